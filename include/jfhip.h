@@ -1,0 +1,185 @@
+/*
+ * libjfhip -- MI355X (gfx950) implementation of the jellyfish PLONK proving hot path:
+ * KZG commit / batch_commit / open (Pippenger MSM) and the radix-2 (coset) NTT / iNTT.
+ *
+ * This is the drop-in boundary: a flat C ABI (plain pointers and sizes) that an FFI crate
+ * binds in place of the reference's ICICLE/CUDA seam.  Each entry point cites the reference
+ * interface it replaces (paths relative to the jellyfish repository root).
+ *
+ * Data conventions (identical to the reference's GPU seam, pcs/src/univariate_kzg/mod.rs:
+ * 967-998 and the zero-copy reinterpret at :815-819):
+ *   - field elements are little-endian u64 limbs in MONTGOMERY form, exactly arkworks'
+ *     in-memory `Fp.0.0` (Fr: 4 limbs; BN254 Fq: 4 limbs; BLS12-381 Fq: 6 limbs);
+ *   - a packed affine G1 point is x limbs followed by y limbs (64 B BN254, 96 B BLS12-381);
+ *     the identity is all-zero limbs (+ the infinity flag where one is carried);
+ *   - every output is fully reduced (< p); NTT data is natural order in and out.
+ *
+ * All functions return JFHIP_OK (0) or a negative status; jfhip_last_error() gives the
+ * message for the calling thread.  No function aborts or throws across the boundary.
+ * Every entry point is thread-safe (the reference enters commit() concurrently from rayon
+ * workers: pcs/src/univariate_kzg/mod.rs:134-136, plonk/src/proof_system/snark.rs:525-534).
+ */
+#ifndef JFHIP_H
+#define JFHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JFHIP_OK 0
+#define JFHIP_ERR_INVALID (-1)  /* maps to PCSError::InvalidParameters (pcs/src/errors.rs:19-34) */
+#define JFHIP_ERR_DEVICE (-2)   /* HIP runtime failure; maps to PCSError::UpstreamError (errors.rs:33-34) */
+#define JFHIP_ERR_NO_DEVICE (-3)
+#define JFHIP_ERR_OOM (-4)
+
+/* curve_id */
+#define JFHIP_BN254 0
+#define JFHIP_BLS12_381 1
+
+typedef struct jfhip_srs jfhip_srs;        /* device-resident prover parameters (powers_of_g) */
+typedef struct jfhip_stream jfhip_stream;  /* a HIP stream + its MSM/NTT workspace */
+
+/* ---- runtime ------------------------------------------------------------------------------ */
+
+/* Select the HIP device this process uses (one process per GPU).  device < 0: keep the
+ * current device.  Replaces nothing in the reference (ICICLE picks device 0 implicitly). */
+int32_t jfhip_init(int32_t device);
+
+/* Copy the calling thread's last error message (NUL-terminated, truncated to len). */
+int32_t jfhip_last_error(char *buf, size_t len);
+
+/* Number of visible HIP devices (0 if none); never fails. */
+int32_t jfhip_device_count(void);
+
+/* Replaces icicle_deps::warmup_new_stream()  (pcs/src/lib.rs:430-435): create a stream and
+ * warm its allocator.  stream == NULL is accepted by every call below and means a
+ * per-thread default stream owned by the library. */
+int32_t jfhip_stream_create(jfhip_stream **out);
+int32_t jfhip_stream_destroy(jfhip_stream *s);
+/* Replaces CudaStream::synchronize()  (pcs/src/univariate_kzg/mod.rs:942). */
+int32_t jfhip_stream_sync(jfhip_stream *s);
+/* The raw hipStream_t of a stream (for callers that enqueue their own HIP work). */
+void *jfhip_stream_raw(jfhip_stream *s);
+/* Wrap an existing hipStream_t (e.g. torch's current stream); the library does not own it. */
+int32_t jfhip_stream_wrap(void *hip_stream, jfhip_stream **out);
+
+/* ---- SRS ---------------------------------------------------------------------------------- */
+
+/* Replaces GPUCommittable::load_prover_param_to_gpu + ark_affine_to_icicle
+ * (pcs/src/univariate_kzg/mod.rs:767-800, 975-980).
+ * points: n host G1Affine records, `stride_bytes` apart, each starting with x limbs then y
+ * limbs (Montgomery).  If stride_bytes > 2*fq_bytes the byte at offset 2*fq_bytes is
+ * arkworks' `infinity: bool`.  The library packs the points, uploads them once and
+ * precomputes the window multiples 2^(c*w) * P_i it needs (kept in HBM; sized for 288 GB),
+ * so later commits need no per-window combine.  window_bits = 0 lets the library choose.
+ * n == 0 is JFHIP_ERR_INVALID (reference :772-778 rejects supported_degree > len-1). */
+int32_t jfhip_srs_load(int32_t curve_id, const void *points, size_t n, size_t stride_bytes, int32_t window_bits,
+                       jfhip_srs **out);
+/* Same, from n packed affine points already in device memory. */
+int32_t jfhip_srs_load_device(int32_t curve_id, const void *d_points_packed, size_t n, int32_t window_bits,
+                              jfhip_srs **out);
+/* Replaces gen_srs_for_testing  (pcs/src/univariate_kzg/srs.rs:175-225) for harnesses:
+ * builds [beta^i] g, i < n, on the device (beta: Fr Montgomery limbs, g: packed affine). */
+int32_t jfhip_srs_gen_for_testing(int32_t curve_id, const uint64_t *beta_mont, const uint64_t *g_xy, size_t n,
+                                  int32_t window_bits, jfhip_srs **out);
+int32_t jfhip_srs_free(jfhip_srs *srs);
+size_t jfhip_srs_len(const jfhip_srs *srs);
+int32_t jfhip_srs_window_bits(const jfhip_srs *srs);
+/* Copy packed affine points [offset, offset+n) of the SRS back to the host. */
+int32_t jfhip_srs_read(const jfhip_srs *srs, size_t offset, size_t n, void *out_points_packed);
+
+/* ---- MSM / KZG commit --------------------------------------------------------------------- */
+
+/* Replaces UnivariateKzgPCS::commit -> E::G1::msm_bigint(&powers_of_g[offset..], coeffs)
+ * .into_affine()  (pcs/src/univariate_kzg/mod.rs:90-125) and the GPU twin
+ * gpu_commit_with_loaded_prover_param (:688-699).
+ * scalars_mont: n Fr elements (Montgomery) in HOST memory; result = sum_i s_i * P[offset+i].
+ * out_xy: packed affine result (host); *out_infinity = 1 for the identity (then out_xy = 0),
+ * which the shim maps to G1Affine::zero() as :989-991 does.
+ * n == 0 yields the identity (zero polynomial).  offset + n > srs length is
+ * JFHIP_ERR_INVALID ("poly degree {} is larger than allowed {}", :100-106).
+ * Synchronous with respect to the host: the result is valid on return. */
+int32_t jfhip_msm(const jfhip_srs *srs, size_t offset, const uint64_t *scalars_mont, size_t n, void *out_xy,
+                  uint8_t *out_infinity, jfhip_stream *stream);
+
+/* Replaces UnivariateKzgPCS::batch_commit (:128-140) / gpu_batch_commit_with_loaded_prover_param
+ * (:731-746): `batch` independent commits against the same SRS, ragged lengths allowed
+ * (the reference zero-pads to the longest, :844-864).  out_xy: batch packed points,
+ * out_infinity: batch flags.  batch == 0 is OK and writes nothing (:706-708). */
+int32_t jfhip_msm_batch(const jfhip_srs *srs, const uint64_t *const *scalars_mont, const size_t *lens, size_t batch,
+                        void *out_xy, uint8_t *out_infinity, jfhip_stream *stream);
+
+/* Replaces commit_on_gpu (:900-930, 1001-1040): scalars already in DEVICE memory
+ * (n Montgomery Fr elements), asynchronous on `stream`; the result is left on the device as
+ * one packed affine point followed by a u32 infinity flag (d_out: 2*fq_bytes + 4 bytes,
+ * 16-byte aligned).  Pair with jfhip_stream_sync + a device->host copy
+ * (load_commitments_to_host, :934-964). */
+int32_t jfhip_msm_device(const jfhip_srs *srs, size_t offset, const void *d_scalars_mont, size_t n, void *d_out,
+                         jfhip_stream *stream);
+
+/* Multi-GPU leg (no counterpart in the reference, which is single-device):
+ * the un-normalised partial sum of this rank's point range as an XYZZ point
+ * (4*fq_bytes, device memory), to be exchanged with RCCL all_gather and folded with
+ * jfhip_g1_sum_partials on every rank. */
+int32_t jfhip_msm_partial_device(const jfhip_srs *srs, size_t offset, const void *d_scalars_mont, size_t n,
+                                 void *d_out_xyzz, jfhip_stream *stream);
+/* Sum `count` XYZZ partials (device) and normalise: d_out as in jfhip_msm_device. */
+int32_t jfhip_g1_sum_partials(int32_t curve_id, const void *d_partials_xyzz, size_t count, void *d_out,
+                              jfhip_stream *stream);
+
+/* Replaces UnivariateKzgPCS::open  (pcs/src/univariate_kzg/mod.rs:144-180): witness
+ * polynomial (f(X) - f(z)) / (X - z) by synthetic division on the device, its commitment,
+ * and eval = f(z).  coeffs_mont: n Fr coefficients (host), point_mont: z (host).
+ * n == 0: proof = identity, eval = 0. */
+int32_t jfhip_kzg_open(const jfhip_srs *srs, const uint64_t *coeffs_mont, size_t n, const uint64_t *point_mont,
+                       void *out_proof_xy, uint8_t *out_infinity, uint64_t *out_eval_mont, jfhip_stream *stream);
+
+/* ---- NTT ---------------------------------------------------------------------------------- */
+
+/* Replaces Radix2EvaluationDomain::{fft, ifft, ifft_in_place} and get_coset(offset).{fft,ifft}
+ * (ark-poly 0.5) at the reference call sites plonk/src/proof_system/prover.rs:534-573,658-660
+ * and relation/src/constraint_system.rs:1369,1386,1418,1437,1454,1464,1473,1482,1491,1573,
+ * 1621-1622.
+ * data: `batch` polynomials, each 2^log_n Fr elements (Montgomery), in HOST memory,
+ * transformed in place, natural order in and out.
+ *   inverse == 0: out[i] = sum_j in[j] * (h * w^i)^j
+ *   inverse != 0: the inverse map (includes the n^{-1} and h^{-j} scaling)
+ * w = Fr::TWO_ADIC_ROOT_OF_UNITY^(2^(s - log_n)); h = *coset_offset_mont, or 1 when NULL.
+ * in_len <= 2^log_n: only the first in_len elements of each polynomial are read, the rest
+ * are taken as zero (ark-poly zero-extends short inputs); in_len == 0 means 2^log_n. */
+int32_t jfhip_ntt(int32_t curve_id, uint64_t *data, uint32_t log_n, size_t batch, int32_t inverse,
+                  const uint64_t *coset_offset_mont, size_t in_len, jfhip_stream *stream);
+/* Same on DEVICE memory, asynchronous on `stream`; d_data holds batch * 2^log_n elements. */
+int32_t jfhip_ntt_device(int32_t curve_id, void *d_data, uint32_t log_n, size_t batch, int32_t inverse,
+                         const uint64_t *coset_offset_mont, size_t in_len, jfhip_stream *stream);
+
+/* ---- field / group vector ops (test and glue surface) -------------------------------------- */
+
+/* field_id: 0 BN254 Fr, 1 BN254 Fq, 2 BLS12-381 Fr, 3 BLS12-381 Fq.
+ * op: 0 add, 1 sub, 2 mul, 3 neg(a), 4 inv(a) (inv(0)=0), 5 from_mont(a), 6 to_mont(a).
+ * Host arrays of n elements; exercises the same device arithmetic the MSM/NTT kernels use. */
+int32_t jfhip_field_op(int32_t field_id, int32_t op, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n);
+
+/* op: 0 out = P + Q (packed affine, host), 1 out = k * P (k: Fr Montgomery, passed as Q). */
+int32_t jfhip_g1_op(int32_t curve_id, int32_t op, const uint64_t *P, const uint64_t *Q, uint64_t *out);
+
+/* Peak-rate probes used by bench.py for the roofline denominators:
+ * kind 0: v_mad_u64_u32 multiply-adds/s (INT32 VALU), kind 1: device copy bytes/s,
+ * kind 2: Montgomery multiplications/s of the field given in `arg` (field_id). */
+int32_t jfhip_probe(int32_t kind, int32_t arg, double *out_rate);
+
+/* Time (ms) the library's kernels of the last MSM / NTT call on this stream took on the
+ * device, per phase, measured with HIP events on the stream the kernels ran on.
+ * phases: caller array of `cap` doubles; returns the number of phases written.
+ * Only recorded while profiling is enabled with jfhip_set_profiling(1). */
+int32_t jfhip_set_profiling(int32_t enabled);
+int32_t jfhip_last_phase_ms(jfhip_stream *stream, double *phases, int32_t cap);
+const char *jfhip_phase_name(int32_t kind /*0 msm, 1 ntt*/, int32_t idx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JFHIP_H */

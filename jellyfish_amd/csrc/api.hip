@@ -1,0 +1,625 @@
+// C ABI of libjfhip (declared in include/jfhip.h): argument checking, host<->device staging,
+// stream / workspace ownership, error strings.  All arithmetic is in msm.hip / ntt.hip /
+// poly.hip; nothing here computes field or group operations on the host.
+#include <stdarg.h>
+
+#include "common.hpp"
+
+namespace jf {
+
+static thread_local std::string t_err;
+static thread_local jfhip_stream* t_default_stream = nullptr;
+static bool g_profiling = false;
+
+void set_error(const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    t_err = buf;
+}
+
+int32_t hip_fail(hipError_t e, const char* what, const char* file, int line) {
+    set_error("HIP error %d (%s) at %s:%d: %s", (int)e, hipGetErrorString(e), file, line, what);
+    if (e == hipErrorOutOfMemory) return JFHIP_ERR_OOM;
+    if (e == hipErrorNoDevice || e == hipErrorInvalidDevice) return JFHIP_ERR_NO_DEVICE;
+    return JFHIP_ERR_DEVICE;
+}
+
+int32_t DevBuf::ensure(size_t bytes) {
+    if (bytes <= cap && p) return JFHIP_OK;
+    if (bytes == 0) bytes = 16;
+    if (p) {
+        JF_HIP(hipDeviceSynchronize());
+        JF_HIP(hipFree(p));
+        p = nullptr;
+        cap = 0;
+    }
+    // round up so slightly larger follow-up problems reuse the allocation
+    size_t want = (bytes + (bytes >> 3) + 255) & ~(size_t)255;
+    JF_HIP(hipMalloc(&p, want));
+    cap = want;
+    return JFHIP_OK;
+}
+void DevBuf::release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+}
+
+bool profiling_enabled() { return g_profiling; }
+
+PhaseTimer::PhaseTimer(jfhip_stream* s, int kind) : st(s), on(g_profiling) {
+    if (!on) return;
+    if (!st->ev_ready) {
+        for (int i = 0; i <= MAX_PHASES; i++)
+            if (hipEventCreate(&st->ev[i]) != hipSuccess) {
+                on = false;
+                return;
+            }
+        st->ev_ready = true;
+    }
+    st->phase_kind = kind;
+    st->n_phases = 0;
+    (void)hipEventRecord(st->ev[0], st->s);
+}
+void PhaseTimer::mark() {
+    if (!on || idx >= MAX_PHASES) return;
+    idx++;
+    (void)hipEventRecord(st->ev[idx], st->s);
+}
+void PhaseTimer::finish() {
+    if (!on) return;
+    st->n_phases = idx;
+}
+
+jfhip_stream* resolve_stream(jfhip_stream* s) {
+    if (s) return s;
+    if (!t_default_stream) {
+        jfhip_stream* st = new jfhip_stream();
+        if (hipStreamCreateWithFlags(&st->s, hipStreamNonBlocking) != hipSuccess) {
+            delete st;
+            return nullptr;
+        }
+        st->owned = true;
+        t_default_stream = st;
+    }
+    return t_default_stream;
+}
+
+static void stream_release(jfhip_stream* s) {
+    DevBuf* bufs[] = {&s->scalars, &s->dig,  &s->sorted, &s->counts, &s->offs,   &s->cursor, &s->bsum,
+                      &s->buckets, &s->partA, &s->partB, &s->red0,   &s->red1,   &s->result, &s->ntt_tmp,
+                      &s->ntt_io,  &s->poly_a, &s->poly_b, &s->poly_c};
+    for (DevBuf* b : bufs) b->release();
+    if (s->ev_ready)
+        for (int i = 0; i <= MAX_PHASES; i++) (void)hipEventDestroy(s->ev[i]);
+    if (s->owned && s->s) (void)hipStreamDestroy(s->s);
+}
+
+static int fq_bytes(int32_t curve) { return fq_limbs32(curve) * 4; }
+
+static int32_t check_curve(int32_t curve) {
+    if (curve != JFHIP_BN254 && curve != JFHIP_BLS12_381) {
+        set_error("unknown curve id %d", curve);
+        return JFHIP_ERR_INVALID;
+    }
+    return JFHIP_OK;
+}
+
+static int32_t srs_alloc(int32_t curve, size_t n, int32_t window_bits, jfhip_srs** out) {
+    JF_TRY(check_curve(curve));
+    if (n == 0) {
+        set_error("SRS must hold at least one point");
+        return JFHIP_ERR_INVALID;
+    }
+    int c = window_bits > 0 ? window_bits : choose_window_bits(curve, n);
+    if (c < 2 || c > 24) {
+        set_error("window_bits %d out of range [2, 24]", c);
+        return JFHIP_ERR_INVALID;
+    }
+    int W = windows_for(curve, c);
+    if ((double)W * (double)n >= 2147483648.0) {
+        set_error("SRS too large: %zu points x %d windows exceeds 2^31 table entries", n, W);
+        return JFHIP_ERR_INVALID;
+    }
+    jfhip_srs* s = new jfhip_srs();
+    s->curve = curve;
+    s->n = n;
+    s->c = c;
+    s->W = W;
+    if (hipGetDevice(&s->device) != hipSuccess) s->device = 0;
+    hipError_t e = hipMalloc(&s->table, (size_t)W * n * 2 * fq_bytes(curve));
+    if (e != hipSuccess) {
+        delete s;
+        return hip_fail(e, "hipMalloc(SRS table)", __FILE__, __LINE__);
+    }
+    *out = s;
+    return JFHIP_OK;
+}
+
+}  // namespace jf
+
+using namespace jf;
+
+#define JF_STREAM(st, s)                                  \
+    jfhip_stream* st = jf::resolve_stream(s);             \
+    if (!st) {                                            \
+        jf::set_error("could not create a HIP stream");   \
+        return JFHIP_ERR_DEVICE;                          \
+    }
+
+extern "C" {
+
+int32_t jfhip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int32_t jfhip_init(int32_t device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0) {
+        set_error("no HIP device visible (%s)", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+        return JFHIP_ERR_NO_DEVICE;
+    }
+    if (device >= 0) {
+        if (device >= n) {
+            set_error("device %d out of range (%d visible)", device, n);
+            return JFHIP_ERR_NO_DEVICE;
+        }
+        JF_HIP(hipSetDevice(device));
+    }
+    JF_HIP(hipFree(nullptr));
+    return JFHIP_OK;
+}
+
+int32_t jfhip_last_error(char* buf, size_t len) {
+    if (!buf || len == 0) return JFHIP_ERR_INVALID;
+    snprintf(buf, len, "%s", t_err.c_str());
+    return JFHIP_OK;
+}
+
+int32_t jfhip_stream_create(jfhip_stream** out) {
+    if (!out) return JFHIP_ERR_INVALID;
+    jfhip_stream* st = new jfhip_stream();
+    hipError_t e = hipStreamCreateWithFlags(&st->s, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete st;
+        return hip_fail(e, "hipStreamCreate", __FILE__, __LINE__);
+    }
+    st->owned = true;
+    // warm the allocator as warmup_new_stream() does (pcs/src/lib.rs:430-435)
+    if (st->result.ensure(4096) != JFHIP_OK) {
+        stream_release(st);
+        delete st;
+        return JFHIP_ERR_DEVICE;
+    }
+    *out = st;
+    return JFHIP_OK;
+}
+
+int32_t jfhip_stream_wrap(void* hip_stream, jfhip_stream** out) {
+    if (!out) return JFHIP_ERR_INVALID;
+    jfhip_stream* st = new jfhip_stream();
+    st->s = (hipStream_t)hip_stream;
+    st->owned = false;
+    *out = st;
+    return JFHIP_OK;
+}
+
+int32_t jfhip_stream_destroy(jfhip_stream* s) {
+    if (!s) return JFHIP_OK;
+    (void)hipStreamSynchronize(s->s);
+    stream_release(s);
+    delete s;
+    return JFHIP_OK;
+}
+
+int32_t jfhip_stream_sync(jfhip_stream* s) {
+    JF_STREAM(st, s);
+    JF_HIP(hipStreamSynchronize(st->s));
+    return JFHIP_OK;
+}
+
+void* jfhip_stream_raw(jfhip_stream* s) {
+    jfhip_stream* st = resolve_stream(s);
+    return st ? (void*)st->s : nullptr;
+}
+
+// ---- SRS ----------------------------------------------------------------------------------------
+
+int32_t jfhip_srs_load(int32_t curve_id, const void* points, size_t n, size_t stride_bytes, int32_t window_bits,
+                       jfhip_srs** out) {
+    if (!points || !out) {
+        set_error("null argument");
+        return JFHIP_ERR_INVALID;
+    }
+    JF_TRY(check_curve(curve_id));
+    const size_t pt = 2 * (size_t)fq_bytes(curve_id);
+    if (stride_bytes < pt) {
+        set_error("stride %zu smaller than a packed point (%zu bytes)", stride_bytes, pt);
+        return JFHIP_ERR_INVALID;
+    }
+    JF_STREAM(st, nullptr);
+    std::lock_guard<std::mutex> lk(st->mu);
+    jfhip_srs* srs = nullptr;
+    JF_TRY(srs_alloc(curve_id, n, window_bits, &srs));
+    DevBuf raw, packed;
+    int32_t rc = raw.ensure(n * stride_bytes);
+    if (rc == JFHIP_OK) rc = packed.ensure(n * pt);
+    if (rc == JFHIP_OK && hipMemcpyAsync(raw.p, points, n * stride_bytes, hipMemcpyHostToDevice, st->s) != hipSuccess)
+        rc = JFHIP_ERR_DEVICE;
+    if (rc == JFHIP_OK) rc = srs_pack_points(curve_id, raw.as<uint8_t>(), n, stride_bytes, packed.as<uint32_t>(), st);
+    if (rc == JFHIP_OK) rc = srs_build_table(srs, packed.as<uint32_t>(), st);
+    if (rc == JFHIP_OK && hipStreamSynchronize(st->s) != hipSuccess) rc = JFHIP_ERR_DEVICE;
+    raw.release();
+    packed.release();
+    if (rc != JFHIP_OK) {
+        jfhip_srs_free(srs);
+        return rc;
+    }
+    *out = srs;
+    return JFHIP_OK;
+}
+
+int32_t jfhip_srs_load_device(int32_t curve_id, const void* d_points_packed, size_t n, int32_t window_bits,
+                              jfhip_srs** out) {
+    if (!d_points_packed || !out) {
+        set_error("null argument");
+        return JFHIP_ERR_INVALID;
+    }
+    JF_STREAM(st, nullptr);
+    std::lock_guard<std::mutex> lk(st->mu);
+    jfhip_srs* srs = nullptr;
+    JF_TRY(srs_alloc(curve_id, n, window_bits, &srs));
+    int32_t rc = srs_build_table(srs, (const uint32_t*)d_points_packed, st);
+    if (rc == JFHIP_OK && hipStreamSynchronize(st->s) != hipSuccess) rc = JFHIP_ERR_DEVICE;
+    if (rc != JFHIP_OK) {
+        jfhip_srs_free(srs);
+        return rc;
+    }
+    *out = srs;
+    return JFHIP_OK;
+}
+
+int32_t jfhip_srs_gen_for_testing(int32_t curve_id, const uint64_t* beta_mont, const uint64_t* g_xy, size_t n,
+                                  int32_t window_bits, jfhip_srs** out) {
+    if (!beta_mont || !g_xy || !out) {
+        set_error("null argument");
+        return JFHIP_ERR_INVALID;
+    }
+    JF_STREAM(st, nullptr);
+    std::lock_guard<std::mutex> lk(st->mu);
+    jfhip_srs* srs = nullptr;
+    JF_TRY(srs_alloc(curve_id, n, window_bits, &srs));
+    // generate straight into window 0 of the table, then extend
+    int32_t rc = srs_gen_points(curve_id, beta_mont, g_xy, n, srs->table, st);
+    if (rc == JFHIP_OK) rc = srs_build_table(srs, srs->table, st);
+    if (rc == JFHIP_OK && hipStreamSynchronize(st->s) != hipSuccess) rc = JFHIP_ERR_DEVICE;
+    if (rc != JFHIP_OK) {
+        jfhip_srs_free(srs);
+        return rc;
+    }
+    *out = srs;
+    return JFHIP_OK;
+}
+
+int32_t jfhip_srs_free(jfhip_srs* srs) {
+    if (!srs) return JFHIP_OK;
+    if (srs->table) (void)hipFree(srs->table);
+    delete srs;
+    return JFHIP_OK;
+}
+
+size_t jfhip_srs_len(const jfhip_srs* srs) { return srs ? srs->n : 0; }
+int32_t jfhip_srs_window_bits(const jfhip_srs* srs) { return srs ? srs->c : 0; }
+
+int32_t jfhip_srs_read(const jfhip_srs* srs, size_t offset, size_t n, void* out) {
+    if (!srs || !out || offset + n > srs->n) {
+        set_error("srs_read: bad range");
+        return JFHIP_ERR_INVALID;
+    }
+    const size_t pt = 2 * (size_t)fq_bytes(srs->curve);
+    JF_HIP(hipMemcpy(out, (const uint8_t*)srs->table + offset * pt, n * pt, hipMemcpyDeviceToHost));
+    return JFHIP_OK;
+}
+
+// ---- MSM ----------------------------------------------------------------------------------------
+
+static int32_t check_msm_range(const jfhip_srs* srs, size_t offset, size_t n) {
+    if (!srs) {
+        set_error("null SRS handle");
+        return JFHIP_ERR_INVALID;
+    }
+    if (offset > srs->n || n > srs->n - offset) {
+        // UnivariateKzgPCS::commit: "poly degree {} is larger than allowed {}" (mod.rs:100-106)
+        set_error("poly degree %zu is larger than allowed %zu", offset + n ? offset + n - 1 : 0, srs->n);
+        return JFHIP_ERR_INVALID;
+    }
+    return JFHIP_OK;
+}
+
+int32_t jfhip_msm_partial_device(const jfhip_srs* srs, size_t offset, const void* d_scalars, size_t n,
+                                 void* d_out_xyzz, jfhip_stream* stream) {
+    JF_TRY(check_msm_range(srs, offset, n));
+    if ((n && !d_scalars) || !d_out_xyzz) {
+        set_error("null argument");
+        return JFHIP_ERR_INVALID;
+    }
+    JF_STREAM(st, stream);
+    std::lock_guard<std::mutex> lk(st->mu);
+    return msm_partial_device(srs, offset, (const uint32_t*)d_scalars, n, (uint32_t*)d_out_xyzz, st);
+}
+
+static int32_t msm_device_locked(const jfhip_srs* srs, size_t offset, const void* d_scalars, size_t n, void* d_out,
+                                 jfhip_stream* st) {
+    const size_t xz = 4 * (size_t)fq_bytes(srs->curve);
+    JF_TRY(st->result.ensure(xz + 256));
+    JF_TRY(msm_partial_device(srs, offset, (const uint32_t*)d_scalars, n, st->result.as<uint32_t>(), st));
+    return g1_sum_to_affine(srs->curve, st->result.as<uint32_t>(), 1, (uint32_t*)d_out, st);
+}
+
+int32_t jfhip_msm_device(const jfhip_srs* srs, size_t offset, const void* d_scalars, size_t n, void* d_out,
+                         jfhip_stream* stream) {
+    JF_TRY(check_msm_range(srs, offset, n));
+    if ((n && !d_scalars) || !d_out) {
+        set_error("null argument");
+        return JFHIP_ERR_INVALID;
+    }
+    JF_STREAM(st, stream);
+    std::lock_guard<std::mutex> lk(st->mu);
+    return msm_device_locked(srs, offset, d_scalars, n, d_out, st);
+}
+
+int32_t jfhip_g1_sum_partials(int32_t curve_id, const void* d_partials, size_t count, void* d_out,
+                              jfhip_stream* stream) {
+    JF_TRY(check_curve(curve_id));
+    if ((count && !d_partials) || !d_out) {
+        set_error("null argument");
+        return JFHIP_ERR_INVALID;
+    }
+    JF_STREAM(st, stream);
+    std::lock_guard<std::mutex> lk(st->mu);
+    if (count == 0) {
+        const size_t bytes = 2 * (size_t)fq_bytes(curve_id);
+        JF_HIP(hipMemsetAsync(d_out, 0, bytes, st->s));
+        uint32_t one = 1;
+        JF_HIP(hipMemcpyAsync((uint8_t*)d_out + bytes, &one, 4, hipMemcpyHostToDevice, st->s));
+        JF_HIP(hipStreamSynchronize(st->s));
+        return JFHIP_OK;
+    }
+    return g1_sum_to_affine(curve_id, (const uint32_t*)d_partials, count, (uint32_t*)d_out, st);
+}
+
+int32_t jfhip_msm_batch(const jfhip_srs* srs, const uint64_t* const* scalars, const size_t* lens, size_t batch,
+                        void* out_xy, uint8_t* out_inf, jfhip_stream* stream) {
+    if (!srs) {
+        set_error("null SRS handle");
+        return JFHIP_ERR_INVALID;
+    }
+    if (batch == 0) return JFHIP_OK;  // gpu_batch_commit: empty input -> Ok(vec![]) (mod.rs:706-708)
+    if (!scalars || !lens || !out_xy || !out_inf) {
+        set_error("null argument");
+        return JFHIP_ERR_INVALID;
+    }
+    size_t maxlen = 0;
+    for (size_t b = 0; b < batch; b++) {
+        JF_TRY(check_msm_range(srs, 0, lens[b]));
+        if (lens[b] && !scalars[b]) {
+            set_error("null scalar pointer for batch entry %zu", b);
+            return JFHIP_ERR_INVALID;
+        }
+        if (lens[b] > maxlen) maxlen = lens[b];
+    }
+    JF_STREAM(st, stream);
+    std::lock_guard<std::mutex> lk(st->mu);
+    const size_t pt = 2 * (size_t)fq_bytes(srs->curve);
+    const size_t rec = (pt + 4 + 15) & ~(size_t)15;
+    JF_TRY(st->scalars.ensure((maxlen ? maxlen : 1) * 32));
+    JF_TRY(st->ntt_io.ensure(batch * rec));  // result records
+    uint8_t* d_res = st->ntt_io.as<uint8_t>();
+    for (size_t b = 0; b < batch; b++) {
+        if (lens[b]) JF_HIP(hipMemcpyAsync(st->scalars.p, scalars[b], lens[b] * 32, hipMemcpyHostToDevice, st->s));
+        JF_TRY(msm_device_locked(srs, 0, st->scalars.p, lens[b], d_res + b * rec, st));
+    }
+    std::vector<uint8_t> host(batch * rec);
+    JF_HIP(hipMemcpyAsync(host.data(), d_res, batch * rec, hipMemcpyDeviceToHost, st->s));
+    JF_HIP(hipStreamSynchronize(st->s));
+    for (size_t b = 0; b < batch; b++) {
+        memcpy((uint8_t*)out_xy + b * pt, host.data() + b * rec, pt);
+        uint32_t inf;
+        memcpy(&inf, host.data() + b * rec + pt, 4);
+        out_inf[b] = inf ? 1 : 0;
+    }
+    return JFHIP_OK;
+}
+
+int32_t jfhip_msm(const jfhip_srs* srs, size_t offset, const uint64_t* scalars, size_t n, void* out_xy,
+                  uint8_t* out_inf, jfhip_stream* stream) {
+    JF_TRY(check_msm_range(srs, offset, n));
+    if ((n && !scalars) || !out_xy || !out_inf) {
+        set_error("null argument");
+        return JFHIP_ERR_INVALID;
+    }
+    JF_STREAM(st, stream);
+    std::lock_guard<std::mutex> lk(st->mu);
+    const size_t pt = 2 * (size_t)fq_bytes(srs->curve);
+    JF_TRY(st->scalars.ensure((n ? n : 1) * 32));
+    JF_TRY(st->ntt_io.ensure(pt + 16));
+    if (n) JF_HIP(hipMemcpyAsync(st->scalars.p, scalars, n * 32, hipMemcpyHostToDevice, st->s));
+    JF_TRY(msm_device_locked(srs, offset, st->scalars.p, n, st->ntt_io.p, st));
+    uint8_t host[160];
+    JF_HIP(hipMemcpyAsync(host, st->ntt_io.p, pt + 4, hipMemcpyDeviceToHost, st->s));
+    JF_HIP(hipStreamSynchronize(st->s));
+    memcpy(out_xy, host, pt);
+    uint32_t inf;
+    memcpy(&inf, host + pt, 4);
+    *out_inf = inf ? 1 : 0;
+    return JFHIP_OK;
+}
+
+int32_t jfhip_kzg_open(const jfhip_srs* srs, const uint64_t* coeffs, size_t n, const uint64_t* point, void* out_xy,
+                       uint8_t* out_inf, uint64_t* out_eval, jfhip_stream* stream) {
+    if (!srs || !point || !out_xy || !out_inf || !out_eval || (n && !coeffs)) {
+        set_error("null argument");
+        return JFHIP_ERR_INVALID;
+    }
+    const size_t pt = 2 * (size_t)fq_bytes(srs->curve);
+    if (n == 0) {
+        memset(out_xy, 0, pt);
+        *out_inf = 1;
+        memset(out_eval, 0, 32);
+        return JFHIP_OK;
+    }
+    JF_TRY(check_msm_range(srs, 0, n - 1));
+    JF_STREAM(st, stream);
+    std::lock_guard<std::mutex> lk(st->mu);
+    JF_TRY(st->poly_a.ensure(n * 32 + 32));
+    JF_TRY(st->poly_c.ensure(n * 32));
+    JF_TRY(st->ntt_io.ensure(pt + 16));
+    uint8_t* d_coeffs = st->poly_a.as<uint8_t>() + 32;
+    JF_HIP(hipMemcpyAsync(st->poly_a.p, point, 32, hipMemcpyHostToDevice, st->s));
+    JF_HIP(hipMemcpyAsync(d_coeffs, coeffs, n * 32, hipMemcpyHostToDevice, st->s));
+    JF_TRY(open_witness_device(srs->curve, (const uint32_t*)d_coeffs, n, st->poly_a.as<uint32_t>(),
+                               st->poly_c.as<uint32_t>(), nullptr, st));
+    // suffix[0] = f(z); suffix[1..n) = witness coefficients
+    JF_TRY(msm_device_locked(srs, 0, st->poly_c.as<uint8_t>() + 32, n - 1, st->ntt_io.p, st));
+    uint8_t host[160];
+    JF_HIP(hipMemcpyAsync(host, st->ntt_io.p, pt + 4, hipMemcpyDeviceToHost, st->s));
+    JF_HIP(hipMemcpyAsync(out_eval, st->poly_c.p, 32, hipMemcpyDeviceToHost, st->s));
+    JF_HIP(hipStreamSynchronize(st->s));
+    memcpy(out_xy, host, pt);
+    uint32_t inf;
+    memcpy(&inf, host + pt, 4);
+    *out_inf = inf ? 1 : 0;
+    return JFHIP_OK;
+}
+
+// ---- NTT ----------------------------------------------------------------------------------------
+
+int32_t jfhip_ntt_device(int32_t curve_id, void* d_data, uint32_t log_n, size_t batch, int32_t inverse,
+                         const uint64_t* coset, size_t in_len, jfhip_stream* stream) {
+    JF_TRY(check_curve(curve_id));
+    if (batch && !d_data) {
+        set_error("null data pointer");
+        return JFHIP_ERR_INVALID;
+    }
+    JF_STREAM(st, stream);
+    std::lock_guard<std::mutex> lk(st->mu);
+    return ntt_device(curve_id, (uint32_t*)d_data, log_n, batch, inverse, coset, in_len, st);
+}
+
+int32_t jfhip_ntt(int32_t curve_id, uint64_t* data, uint32_t log_n, size_t batch, int32_t inverse,
+                  const uint64_t* coset, size_t in_len, jfhip_stream* stream) {
+    JF_TRY(check_curve(curve_id));
+    if (batch == 0) return JFHIP_OK;
+    if (!data) {
+        set_error("null data pointer");
+        return JFHIP_ERR_INVALID;
+    }
+    if (log_n > 30) {
+        set_error("ntt: log_n %u too large", log_n);
+        return JFHIP_ERR_INVALID;
+    }
+    JF_STREAM(st, stream);
+    std::lock_guard<std::mutex> lk(st->mu);
+    const size_t n = (size_t)1 << log_n;
+    if (in_len == 0 || in_len > n) in_len = n;
+    const size_t bytes = batch * n * 32;
+    JF_TRY(st->ntt_io.ensure(bytes));
+    if (in_len == n) {
+        JF_HIP(hipMemcpyAsync(st->ntt_io.p, data, bytes, hipMemcpyHostToDevice, st->s));
+    } else {
+        // only the first in_len elements of each polynomial cross PCIe
+        JF_HIP(hipMemcpy2DAsync(st->ntt_io.p, n * 32, data, n * 32, in_len * 32, batch, hipMemcpyHostToDevice,
+                                st->s));
+        if (log_n == 0) in_len = n;
+    }
+    JF_TRY(ntt_device(curve_id, st->ntt_io.as<uint32_t>(), log_n, batch, inverse, coset, in_len, st));
+    JF_HIP(hipMemcpyAsync(data, st->ntt_io.p, bytes, hipMemcpyDeviceToHost, st->s));
+    JF_HIP(hipStreamSynchronize(st->s));
+    return JFHIP_OK;
+}
+
+// ---- field / group test surface ---------------------------------------------------------------------
+
+int32_t jfhip_field_op(int32_t field_id, int32_t op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
+    if (field_id < 0 || field_id > 3 || op < 0 || op > 6) {
+        set_error("bad field id / op");
+        return JFHIP_ERR_INVALID;
+    }
+    if (n == 0) return JFHIP_OK;
+    if (!a || !out || (op <= 2 && !b)) {
+        set_error("null argument");
+        return JFHIP_ERR_INVALID;
+    }
+    JF_STREAM(st, nullptr);
+    std::lock_guard<std::mutex> lk(st->mu);
+    const size_t el = field_id == 3 ? 48 : 32;
+    JF_TRY(st->poly_a.ensure(n * el));
+    JF_TRY(st->poly_b.ensure(n * el));
+    JF_TRY(st->poly_c.ensure(n * el));
+    JF_HIP(hipMemcpyAsync(st->poly_a.p, a, n * el, hipMemcpyHostToDevice, st->s));
+    if (op <= 2) JF_HIP(hipMemcpyAsync(st->poly_b.p, b, n * el, hipMemcpyHostToDevice, st->s));
+    JF_TRY(field_op_device(field_id, op, st->poly_a.as<uint32_t>(), st->poly_b.as<uint32_t>(),
+                           st->poly_c.as<uint32_t>(), n, st->s));
+    JF_HIP(hipMemcpyAsync(out, st->poly_c.p, n * el, hipMemcpyDeviceToHost, st->s));
+    JF_HIP(hipStreamSynchronize(st->s));
+    return JFHIP_OK;
+}
+
+int32_t jfhip_g1_op(int32_t curve_id, int32_t op, const uint64_t* P, const uint64_t* Q, uint64_t* out) {
+    JF_TRY(check_curve(curve_id));
+    if (!P || !Q || !out || op < 0 || op > 1) {
+        set_error("bad argument");
+        return JFHIP_ERR_INVALID;
+    }
+    JF_STREAM(st, nullptr);
+    std::lock_guard<std::mutex> lk(st->mu);
+    const size_t pt = 2 * (size_t)fq_bytes(curve_id);
+    JF_TRY(st->poly_a.ensure(3 * pt));
+    uint8_t* d = st->poly_a.as<uint8_t>();
+    JF_HIP(hipMemcpyAsync(d, P, pt, hipMemcpyHostToDevice, st->s));
+    JF_HIP(hipMemcpyAsync(d + pt, Q, op == 0 ? pt : 32, hipMemcpyHostToDevice, st->s));
+    JF_TRY(g1_op_device(curve_id, op, (uint32_t*)d, (uint32_t*)(d + pt), (uint32_t*)(d + 2 * pt), st->s));
+    JF_HIP(hipMemcpyAsync(out, d + 2 * pt, pt, hipMemcpyDeviceToHost, st->s));
+    JF_HIP(hipStreamSynchronize(st->s));
+    return JFHIP_OK;
+}
+
+int32_t jfhip_probe(int32_t kind, int32_t arg, double* out_rate) {
+    if (!out_rate) return JFHIP_ERR_INVALID;
+    return probe(kind, arg, out_rate);
+}
+
+int32_t jfhip_set_profiling(int32_t enabled) {
+    g_profiling = enabled != 0;
+    return JFHIP_OK;
+}
+
+int32_t jfhip_last_phase_ms(jfhip_stream* stream, double* phases, int32_t cap) {
+    jfhip_stream* st = resolve_stream(stream);
+    if (!st || !phases || !st->ev_ready) return 0;
+    std::lock_guard<std::mutex> lk(st->mu);
+    if (hipStreamSynchronize(st->s) != hipSuccess) return 0;
+    int n = st->n_phases < cap ? st->n_phases : cap;
+    for (int i = 0; i < n; i++) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, st->ev[i], st->ev[i + 1]) != hipSuccess) ms = -1.f;
+        phases[i] = ms;
+    }
+    return n;
+}
+
+const char* jfhip_phase_name(int32_t kind, int32_t idx) {
+    static const char* msm[] = {"digits+histogram", "scan+scatter", "bucket_accumulate", "slice_fixup",
+                                "bucket_fold",      "sum_tree"};
+    if (kind == 0) return (idx >= 0 && idx < 6) ? msm[idx] : "";
+    static const char* ntt[] = {"pass0", "pass1", "pass2", "pass3"};
+    return (idx >= 0 && idx < 4) ? ntt[idx] : "";
+}
+
+}  // extern "C"

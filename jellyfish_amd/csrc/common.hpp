@@ -1,0 +1,110 @@
+// Host-side plumbing shared by the libjfhip translation units: error reporting, streams
+// with their device workspaces, phase timing.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/jfhip.h"
+
+namespace jf {
+
+void set_error(const char* fmt, ...);
+int32_t hip_fail(hipError_t e, const char* what, const char* file, int line);
+
+#define JF_HIP(expr)                                                       \
+    do {                                                                   \
+        hipError_t _e = (expr);                                            \
+        if (_e != hipSuccess) return jf::hip_fail(_e, #expr, __FILE__, __LINE__); \
+    } while (0)
+
+#define JF_TRY(expr)                 \
+    do {                             \
+        int32_t _rc = (expr);        \
+        if (_rc != JFHIP_OK) return _rc; \
+    } while (0)
+
+// growable device buffer (grow-only; reallocation synchronises the device)
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int32_t ensure(size_t bytes);
+    void release();
+    template <class T>
+    T* as() const {
+        return reinterpret_cast<T*>(p);
+    }
+};
+
+constexpr int MAX_PHASES = 16;
+
+}  // namespace jf
+
+struct jfhip_stream {
+    hipStream_t s = nullptr;
+    bool owned = false;
+    std::mutex mu;  // one MSM/NTT at a time per stream object (workspace is per stream)
+    // MSM workspace
+    jf::DevBuf scalars, dig, sorted, counts, offs, cursor, bsum, buckets, partA, partB, red0, red1, result;
+    // NTT workspace
+    jf::DevBuf ntt_tmp, ntt_io;
+    // open()
+    jf::DevBuf poly_a, poly_b, poly_c;
+    // phase timing
+    hipEvent_t ev[jf::MAX_PHASES + 1] = {};
+    bool ev_ready = false;
+    int n_phases = 0;
+    int phase_kind = 0;
+};
+
+struct jfhip_srs {
+    int32_t curve = 0;
+    size_t n = 0;       // points
+    int32_t c = 0;      // window bits
+    int32_t W = 0;      // windows
+    int device = 0;
+    uint32_t* table = nullptr;  // [W][n] packed affine, entry (w, i) = 2^(c*w) * P_i
+};
+
+namespace jf {
+
+jfhip_stream* resolve_stream(jfhip_stream* s);  // NULL -> per-thread default
+bool profiling_enabled();
+
+struct PhaseTimer {
+    jfhip_stream* st;
+    bool on;
+    int idx = 0;
+    PhaseTimer(jfhip_stream* s, int kind);
+    void mark();  // records the boundary after the phase just enqueued
+    void finish();
+};
+
+// per-curve / per-field entry points implemented in msm.hip / ntt.hip / poly.hip
+int32_t msm_partial_device(const jfhip_srs* srs, size_t offset, const uint32_t* d_scalars, size_t n,
+                           uint32_t* d_out_xyzz, jfhip_stream* st);
+int32_t g1_sum_to_affine(int32_t curve, const uint32_t* d_partials, size_t count, uint32_t* d_out, jfhip_stream* st);
+int32_t srs_build_table(jfhip_srs* srs, const uint32_t* d_points_packed, jfhip_stream* st);
+int32_t srs_gen_points(int32_t curve, const uint64_t* beta_mont, const uint64_t* g_xy, size_t n, uint32_t* d_out,
+                       jfhip_stream* st);
+int32_t srs_pack_points(int32_t curve, const uint8_t* d_raw, size_t n, size_t stride, uint32_t* d_out,
+                        jfhip_stream* st);
+int32_t ntt_device(int32_t curve, uint32_t* d_data, uint32_t log_n, size_t batch, int inverse,
+                   const uint64_t* coset_mont, size_t in_len, jfhip_stream* st);
+int32_t open_witness_device(int32_t curve, const uint32_t* d_coeffs, size_t n, const uint32_t* d_point,
+                            uint32_t* d_witness, uint32_t* d_eval, jfhip_stream* st);
+int32_t field_op_device(int32_t field_id, int32_t op, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t n,
+                        hipStream_t s);
+int32_t g1_op_device(int32_t curve, int32_t op, const uint32_t* P, const uint32_t* Q, uint32_t* out, hipStream_t s);
+int32_t probe(int32_t kind, int32_t arg, double* out);
+
+inline int fq_limbs32(int32_t curve) { return curve == JFHIP_BN254 ? 8 : 12; }
+int choose_window_bits(int32_t curve, size_t n);
+int windows_for(int32_t curve, int c);
+
+}  // namespace jf

@@ -1,0 +1,352 @@
+// Montgomery prime-field arithmetic on 32-bit limbs for gfx950 VALU.
+//
+// Representation = arkworks' in-memory Fp (Montgomery form, R = 2^(32*N), little-endian
+// limbs; reference pcs/src/univariate_kzg/mod.rs:970-979 hands over exactly `x.0.0`), so
+// host buffers are consumed and produced without conversion.  All results are fully
+// reduced (< p), as arkworks requires of stored values.
+//
+// The multiplier is v_mad_u64_u32 (32x32+64 -> 64); every field here has at least one
+// spare top bit (p < 2^(32N-1)), so the CIOS "no-carry" variant needs only N+1 limbs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace jf {
+
+#define JF_DEV __device__ __forceinline__
+#define JF_HD __host__ __device__ __forceinline__
+
+// ---- field parameter packs -------------------------------------------------------------
+struct Bn254Fr {
+    static constexpr int N = 8;
+    static constexpr uint32_t INV = 0xefffffffu;
+    static constexpr int BITS = 254;
+    JF_HD static constexpr uint32_t P(int i) {
+        constexpr uint32_t p[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u,
+                                   0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+        return p[i];
+    }
+    // R mod p
+    JF_HD static constexpr uint32_t ONE(int i) {
+        constexpr uint32_t v[8] = {0x4ffffffbu, 0xac96341cu, 0x9f60cd29u, 0x36fc7695u,
+                                   0x7879462eu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
+        return v[i];
+    }
+    // R^2 mod p
+    JF_HD static constexpr uint32_t R2(int i) {
+        constexpr uint32_t v[8] = {0xae216da7u, 0x1bb8e645u, 0xe35c59e3u, 0x53fe3ab1u,
+                                   0x53bb8085u, 0x8c49833du, 0x7f4e44a5u, 0x0216d0b1u};
+        return v[i];
+    }
+};
+struct Bn254Fq {
+    static constexpr int N = 8;
+    static constexpr uint32_t INV = 0xe4866389u;
+    static constexpr int BITS = 254;
+    JF_HD static constexpr uint32_t P(int i) {
+        constexpr uint32_t p[8] = {0xd87cfd47u, 0x3c208c16u, 0x6871ca8du, 0x97816a91u,
+                                   0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+        return p[i];
+    }
+    JF_HD static constexpr uint32_t ONE(int i) {
+        constexpr uint32_t v[8] = {0xc58f0d9du, 0xd35d438du, 0xf5c70b3du, 0x0a78eb28u,
+                                   0x7879462cu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
+        return v[i];
+    }
+    JF_HD static constexpr uint32_t R2(int i) {
+        constexpr uint32_t v[8] = {0x538afa89u, 0xf32cfc5bu, 0xd44501fbu, 0xb5e71911u,
+                                   0x0a417ff6u, 0x47ab1effu, 0xcab8351fu, 0x06d89f71u};
+        return v[i];
+    }
+};
+struct Bls381Fr {
+    static constexpr int N = 8;
+    static constexpr uint32_t INV = 0xffffffffu;
+    static constexpr int BITS = 255;
+    JF_HD static constexpr uint32_t P(int i) {
+        constexpr uint32_t p[8] = {0x00000001u, 0xffffffffu, 0xfffe5bfeu, 0x53bda402u,
+                                   0x09a1d805u, 0x3339d808u, 0x299d7d48u, 0x73eda753u};
+        return p[i];
+    }
+    JF_HD static constexpr uint32_t ONE(int i) {
+        constexpr uint32_t v[8] = {0xfffffffeu, 0x00000001u, 0x00034802u, 0x5884b7fau,
+                                   0xecbc4ff5u, 0x998c4fefu, 0xacc5056fu, 0x1824b159u};
+        return v[i];
+    }
+    JF_HD static constexpr uint32_t R2(int i) {
+        constexpr uint32_t v[8] = {0xf3f29c6du, 0xc999e990u, 0x87925c23u, 0x2b6cedcbu,
+                                   0x7254398fu, 0x05d31496u, 0x9f59ff11u, 0x0748d9d9u};
+        return v[i];
+    }
+};
+struct Bls381Fq {
+    static constexpr int N = 12;
+    static constexpr uint32_t INV = 0xfffcfffdu;
+    static constexpr int BITS = 381;
+    JF_HD static constexpr uint32_t P(int i) {
+        constexpr uint32_t p[12] = {0xffffaaabu, 0xb9feffffu, 0xb153ffffu, 0x1eabfffeu, 0xf6b0f624u, 0x6730d2a0u,
+                                    0xf38512bfu, 0x64774b84u, 0x434bacd7u, 0x4b1ba7b6u, 0x397fe69au, 0x1a0111eau};
+        return p[i];
+    }
+    JF_HD static constexpr uint32_t ONE(int i) {
+        constexpr uint32_t v[12] = {0x0002fffdu, 0x76090000u, 0xc40c0002u, 0xebf4000bu, 0x53c758bau, 0x5f489857u,
+                                    0x70525745u, 0x77ce5853u, 0xa256ec6du, 0x5c071a97u, 0xfa80e493u, 0x15f65ec3u};
+        return v[i];
+    }
+    JF_HD static constexpr uint32_t R2(int i) {
+        constexpr uint32_t v[12] = {0x1c341746u, 0xf4df1f34u, 0x09d104f1u, 0x0a76e6a6u, 0x4c95b6d5u, 0x8de5476cu,
+                                    0x939d83c0u, 0x67eb88a9u, 0xb519952du, 0x9a793e85u, 0x92cae3aau, 0x11988fe5u};
+        return v[i];
+    }
+};
+
+// ---- element type ----------------------------------------------------------------------
+template <class C>
+struct Fp {
+    static constexpr int N = C::N;
+    uint32_t v[C::N];
+
+    JF_HD static Fp zero() {
+        Fp r;
+#pragma unroll
+        for (int i = 0; i < N; i++) r.v[i] = 0;
+        return r;
+    }
+    JF_HD static Fp one() {
+        Fp r;
+#pragma unroll
+        for (int i = 0; i < N; i++) r.v[i] = C::ONE(i);
+        return r;
+    }
+    JF_HD static Fp r2() {
+        Fp r;
+#pragma unroll
+        for (int i = 0; i < N; i++) r.v[i] = C::R2(i);
+        return r;
+    }
+    JF_HD bool is_zero() const {
+        uint32_t t = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) t |= v[i];
+        return t == 0;
+    }
+    JF_HD bool operator==(const Fp& o) const {
+        uint32_t t = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) t |= v[i] ^ o.v[i];
+        return t == 0;
+    }
+    JF_HD bool operator!=(const Fp& o) const { return !(*this == o); }
+};
+
+// r = a - p if a >= p (a < 2p)
+template <class C>
+JF_HD Fp<C> fp_reduce_once(const Fp<C>& a) {
+    constexpr int N = C::N;
+    Fp<C> s;
+    uint32_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        uint64_t d = (uint64_t)a.v[i] - C::P(i) - borrow;
+        s.v[i] = (uint32_t)d;
+        borrow = (uint32_t)(d >> 32) & 1u;
+    }
+    Fp<C> r;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.v[i] = borrow ? a.v[i] : s.v[i];
+    return r;
+}
+
+template <class C>
+JF_HD Fp<C> fp_add(const Fp<C>& a, const Fp<C>& b) {
+    constexpr int N = C::N;
+    Fp<C> t;
+    uint32_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        uint64_t s = (uint64_t)a.v[i] + b.v[i] + carry;
+        t.v[i] = (uint32_t)s;
+        carry = (uint32_t)(s >> 32);
+    }
+    // p < 2^(32N-1) so a+b never overflows N limbs
+    return fp_reduce_once<C>(t);
+}
+
+template <class C>
+JF_HD Fp<C> fp_sub(const Fp<C>& a, const Fp<C>& b) {
+    constexpr int N = C::N;
+    Fp<C> t;
+    uint32_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        uint64_t d = (uint64_t)a.v[i] - b.v[i] - borrow;
+        t.v[i] = (uint32_t)d;
+        borrow = (uint32_t)(d >> 32) & 1u;
+    }
+    uint32_t mask = 0u - borrow;
+    uint32_t carry = 0;
+    Fp<C> r;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        uint64_t s = (uint64_t)t.v[i] + (C::P(i) & mask) + carry;
+        r.v[i] = (uint32_t)s;
+        carry = (uint32_t)(s >> 32);
+    }
+    return r;
+}
+
+template <class C>
+JF_HD Fp<C> fp_neg(const Fp<C>& a) {
+    constexpr int N = C::N;
+    Fp<C> r;
+    uint32_t borrow = 0;
+    uint32_t nz = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) nz |= a.v[i];
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        uint64_t d = (uint64_t)C::P(i) - a.v[i] - borrow;
+        r.v[i] = nz ? (uint32_t)d : 0u;
+        borrow = (uint32_t)(d >> 32) & 1u;
+    }
+    return r;
+}
+
+template <class C>
+JF_HD Fp<C> fp_dbl(const Fp<C>& a) {
+    constexpr int N = C::N;
+    Fp<C> t;
+    uint32_t hi = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        t.v[i] = (a.v[i] << 1) | hi;
+        hi = a.v[i] >> 31;
+    }
+    return fp_reduce_once<C>(t);
+}
+
+// CIOS Montgomery product, operand-scanning, one 64-bit accumulator chain per row.
+template <class C>
+JF_HD Fp<C> fp_mul(const Fp<C>& a, const Fp<C>& b) {
+    constexpr int N = C::N;
+    uint32_t t[N + 1];
+#pragma unroll
+    for (int i = 0; i <= N; i++) t[i] = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        uint64_t c = 0;
+        const uint32_t bi = b.v[i];
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+            c = (uint64_t)a.v[j] * bi + t[j] + c;
+            t[j] = (uint32_t)c;
+            c >>= 32;
+        }
+        uint32_t tn = t[N] + (uint32_t)c;  // no-carry: fits 32 bits
+        const uint32_t m = t[0] * C::INV;
+        c = (uint64_t)m * C::P(0) + t[0];
+        c >>= 32;
+#pragma unroll
+        for (int j = 1; j < N; j++) {
+            c = (uint64_t)m * C::P(j) + t[j] + c;
+            t[j - 1] = (uint32_t)c;
+            c >>= 32;
+        }
+        c += tn;
+        t[N - 1] = (uint32_t)c;
+        t[N] = (uint32_t)(c >> 32);
+    }
+    Fp<C> r;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.v[i] = t[i];
+    return fp_reduce_once<C>(r);
+}
+
+template <class C>
+JF_HD Fp<C> fp_sqr(const Fp<C>& a) {
+    return fp_mul<C>(a, a);
+}
+
+// Montgomery reduction of a single N-limb value: a * R^{-1} mod p  (Montgomery -> canonical)
+template <class C>
+JF_HD Fp<C> fp_from_mont(const Fp<C>& a) {
+    constexpr int N = C::N;
+    uint32_t t[N + 1];
+#pragma unroll
+    for (int i = 0; i < N; i++) t[i] = a.v[i];
+    t[N] = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const uint32_t m = t[0] * C::INV;
+        uint64_t c = (uint64_t)m * C::P(0) + t[0];
+        c >>= 32;
+#pragma unroll
+        for (int j = 1; j < N; j++) {
+            c = (uint64_t)m * C::P(j) + t[j] + c;
+            t[j - 1] = (uint32_t)c;
+            c >>= 32;
+        }
+        t[N - 1] = (uint32_t)c;
+    }
+    Fp<C> r;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.v[i] = t[i];
+    return fp_reduce_once<C>(r);
+}
+
+template <class C>
+JF_HD Fp<C> fp_to_mont(const Fp<C>& a) {
+    return fp_mul<C>(a, Fp<C>::r2());
+}
+
+// a^(p-2) (Fermat); inv(0) = 0.  Exponent bits come from the constexpr modulus.
+template <class C>
+JF_HD Fp<C> fp_inv(const Fp<C>& a) {
+    constexpr int N = C::N;
+    Fp<C> acc = Fp<C>::one();
+    // p - 2 : only limb 0 changes for every modulus here (low limb >= 2)
+    for (int i = N - 1; i >= 0; i--) {
+        uint32_t e = C::P(i) - (i == 0 ? 2u : 0u);
+        for (int b = 31; b >= 0; b--) {
+            acc = fp_sqr<C>(acc);
+            if ((e >> b) & 1u) acc = fp_mul<C>(acc, a);
+        }
+    }
+    return acc;
+}
+
+// small-exponent power
+template <class C>
+JF_HD Fp<C> fp_pow_u64(Fp<C> base, uint64_t e) {
+    Fp<C> acc = Fp<C>::one();
+    while (e) {
+        if (e & 1) acc = fp_mul<C>(acc, base);
+        base = fp_sqr<C>(base);
+        e >>= 1;
+    }
+    return acc;
+}
+
+// ---- global-memory access: N limbs as 16-byte vectors -----------------------------------
+template <class C>
+JF_DEV Fp<C> fp_load(const uint32_t* __restrict__ p) {
+    Fp<C> r;
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+#pragma unroll
+    for (int i = 0; i < C::N / 4; i++) {
+        uint4 t = q[i];
+        r.v[4 * i] = t.x;
+        r.v[4 * i + 1] = t.y;
+        r.v[4 * i + 2] = t.z;
+        r.v[4 * i + 3] = t.w;
+    }
+    return r;
+}
+template <class C>
+JF_DEV void fp_store(uint32_t* __restrict__ p, const Fp<C>& a) {
+    uint4* q = reinterpret_cast<uint4*>(p);
+#pragma unroll
+    for (int i = 0; i < C::N / 4; i++) q[i] = make_uint4(a.v[4 * i], a.v[4 * i + 1], a.v[4 * i + 2], a.v[4 * i + 3]);
+}
+
+}  // namespace jf

@@ -1,0 +1,710 @@
+// Pippenger multi-scalar multiplication for gfx950, the arithmetic behind
+// UnivariateKzgPCS::commit / batch_commit / open (reference call sites
+// pcs/src/univariate_kzg/mod.rs:114-118,166-170: E::G1::msm_bigint(..).into_affine()).
+//
+// MI355X-first design:
+//   * the SRS handle holds table[w][i] = 2^(c*w) * P_i for every window w (288 GB of HBM
+//     makes W copies of the SRS cheap), so all windows share ONE bucket space of
+//     2^(c-1) buckets and no per-window Horner combine exists;
+//   * scalars arrive in Montgomery form; the Montgomery reduction is fused into the
+//     signed-digit decomposition (reference mod.rs:1044-1066 does it on the host);
+//   * (bucket, table index) pairs are bucket-sorted on the device, then the sorted list is
+//     cut into equal slices, one per lane, so every lane performs the same number of mixed
+//     additions whatever the scalar distribution; runs that straddle a slice boundary are
+//     stitched by a fix-up pass;
+//   * buckets are folded by sum_k k*B_k = running sums per lane + a tree.
+// All group arithmetic is exact (curve.hpp), so the affine result is the unique group
+// element and equals arkworks' bit for bit.
+#include "common.hpp"
+#include "curve.hpp"
+
+namespace jf {
+
+// ------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------
+
+// bits [bit, bit+c) of an 8-limb integer, c <= 24, without dynamic register indexing
+template <int N>
+JF_DEV uint32_t extract_bits(const uint32_t (&v)[N], int bit, int c) {
+    const int limb = bit >> 5, sh = bit & 31;
+    uint32_t lo = 0, hi = 0;
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        lo = (j == limb) ? v[j] : lo;
+        hi = (j == limb + 1) ? v[j] : hi;
+    }
+    uint64_t t = ((uint64_t)hi << 32) | lo;
+    return (uint32_t)(t >> sh) & ((1u << c) - 1u);
+}
+
+// scalar (Montgomery) -> W signed digits in [-2^(c-1), 2^(c-1)]; histogram of |digit|-1
+template <class Cv>
+__global__ __launch_bounds__(256) void k_msm_digits(const uint32_t* __restrict__ scalars, uint32_t n, int c, int W,
+                                                    int32_t* __restrict__ dig, uint32_t* __restrict__ count) {
+    using Fr = typename Cv::Fr;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fp<Fr> s = fp_from_mont<Fr>(fp_load<Fr>(scalars + (size_t)i * Fr::N));
+    uint32_t carry = 0;
+    const uint32_t half = 1u << (c - 1);
+    for (int w = 0; w < W; w++) {
+        int bit = w * c;
+        uint32_t raw = (bit < 32 * Fr::N) ? extract_bits<Fr::N>(s.v, bit, c) : 0u;
+        raw += carry;
+        int32_t d;
+        if (raw > half) {
+            d = (int32_t)raw - (int32_t)(1u << c);
+            carry = 1;
+        } else {
+            d = (int32_t)raw;
+            carry = 0;
+        }
+        dig[(size_t)w * n + i] = d;
+        if (d != 0) atomicAdd(&count[(d < 0 ? -d : d) - 1], 1u);
+    }
+}
+
+// ---- exclusive scan of the bucket histogram (3 small launches) ----------------------------
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_BLOCK = 256;
+
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_local(const uint32_t* __restrict__ in, uint32_t n,
+                                                           uint32_t* __restrict__ out, uint32_t* __restrict__ bsum) {
+    __shared__ uint32_t sh[SCAN_BLOCK];
+    uint32_t base = (blockIdx.x * SCAN_BLOCK + threadIdx.x) * SCAN_ITEMS;
+    uint32_t v[SCAN_ITEMS];
+    uint32_t tot = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+        v[k] = (base + k < n) ? in[base + k] : 0u;
+        tot += v[k];
+    }
+    sh[threadIdx.x] = tot;
+    __syncthreads();
+    for (int d = 1; d < SCAN_BLOCK; d <<= 1) {
+        uint32_t t = (threadIdx.x >= (unsigned)d) ? sh[threadIdx.x - d] : 0u;
+        __syncthreads();
+        sh[threadIdx.x] += t;
+        __syncthreads();
+    }
+    uint32_t excl = sh[threadIdx.x] - tot;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+        if (base + k < n) out[base + k] = excl;
+        excl += v[k];
+    }
+    if (threadIdx.x == SCAN_BLOCK - 1) bsum[blockIdx.x] = sh[threadIdx.x];
+}
+
+// single block: exclusive scan of the block sums in place; total -> out_total
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_top(uint32_t* __restrict__ bsum, uint32_t nblk,
+                                                         uint32_t* __restrict__ out_total) {
+    __shared__ uint32_t sh[SCAN_BLOCK];
+    uint32_t per = (nblk + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    uint32_t lo = threadIdx.x * per;
+    uint32_t tot = 0;
+    for (uint32_t k = 0; k < per; k++)
+        if (lo + k < nblk) tot += bsum[lo + k];
+    sh[threadIdx.x] = tot;
+    __syncthreads();
+    for (int d = 1; d < SCAN_BLOCK; d <<= 1) {
+        uint32_t t = (threadIdx.x >= (unsigned)d) ? sh[threadIdx.x - d] : 0u;
+        __syncthreads();
+        sh[threadIdx.x] += t;
+        __syncthreads();
+    }
+    uint32_t excl = sh[threadIdx.x] - tot;
+    for (uint32_t k = 0; k < per; k++)
+        if (lo + k < nblk) {
+            uint32_t t = bsum[lo + k];
+            bsum[lo + k] = excl;
+            excl += t;
+        }
+    if (threadIdx.x == SCAN_BLOCK - 1) *out_total = sh[threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void k_scan_add(uint32_t* __restrict__ off, uint32_t n,
+                                                  const uint32_t* __restrict__ bsum, uint32_t* __restrict__ cursor) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t v = off[i] + bsum[i / (SCAN_BLOCK * SCAN_ITEMS)];
+    off[i] = v;
+    cursor[i] = v;
+}
+
+// bucket-sort scatter: entry = table index | sign << 31
+__global__ __launch_bounds__(256) void k_msm_scatter(const int32_t* __restrict__ dig, uint32_t n, int W,
+                                                     uint32_t table_n, uint32_t offset,
+                                                     uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t total = (size_t)n * W;
+    if (idx >= total) return;
+    int32_t d = dig[idx];
+    if (d == 0) return;
+    uint32_t w = (uint32_t)(idx / n), i = (uint32_t)(idx % n);
+    uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1u;
+    uint32_t pos = atomicAdd(&cursor[b], 1u);
+    sorted[pos] = (w * table_n + offset + i) | (d < 0 ? 0x80000000u : 0u);
+}
+
+// One lane per slice of L consecutive sorted entries.  A run (maximal stretch of one bucket
+// inside a slice) that covers its whole bucket is final and goes to buckets[b]; a run cut
+// by a slice boundary goes to partA[t] (it contains the slice's first entry) or partB[t]
+// (it does not) and is stitched by k_msm_fixup.
+template <class Cv>
+__global__ __launch_bounds__(128) void k_msm_accumulate(const uint32_t* __restrict__ sorted,
+                                                        const uint32_t* __restrict__ off, uint32_t B,
+                                                        const uint32_t* __restrict__ table, uint32_t L,
+                                                        uint32_t* __restrict__ buckets, uint32_t* __restrict__ partA,
+                                                        uint32_t* __restrict__ partB) {
+    using Q = typename Cv::Fq;
+    constexpr int PT = 2 * Q::N;  // limbs per packed affine point
+    constexpr int XZ = 4 * Q::N;  // limbs per XYZZ point
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t total = off[B];
+    const uint64_t start64 = (uint64_t)t * L;
+    if (start64 >= total) return;
+    const uint32_t start = (uint32_t)start64;
+    const uint32_t end = (uint32_t)((start64 + L < total) ? start64 + L : total);
+
+    // bucket containing `start`: largest b with off[b] <= start (and off[b+1] > start)
+    uint32_t lo = 0, hi = B;
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (off[mid] <= start) lo = mid;
+        else hi = mid;
+    }
+    uint32_t b = lo;
+    uint32_t b_lo = off[b], b_hi = off[b + 1];
+    while (b_hi <= start) {  // skip empty buckets sharing the same offset
+        b++;
+        b_lo = b_hi;
+        b_hi = off[b + 1];
+    }
+
+    XYZZ<Cv> acc = XYZZ<Cv>::identity();
+    uint32_t run_start = start;
+    bool wroteA = false, wroteB = false;
+
+    auto flush = [&](uint32_t run_end) {
+        bool complete = (run_start == b_lo) && (run_end == b_hi);
+        uint32_t* dst;
+        if (complete) dst = buckets + (size_t)b * XZ;
+        else if (run_start == start) {
+            dst = partA + (size_t)t * XZ;
+            wroteA = true;
+        } else {
+            dst = partB + (size_t)t * XZ;
+            wroteB = true;
+        }
+        xyzz_store<Cv>(dst, acc);
+    };
+
+    for (uint32_t pos = start; pos < end; pos++) {
+        if (pos >= b_hi) {
+            flush(pos);
+            acc = XYZZ<Cv>::identity();
+            run_start = pos;
+            do {
+                b++;
+                b_lo = b_hi;
+                b_hi = off[b + 1];
+            } while (pos >= b_hi);
+        }
+        uint32_t e = sorted[pos];
+        Affine<Cv> p = affine_load<Cv>(table + (size_t)(e & 0x7fffffffu) * PT);
+        if (e >> 31) p.y = fp_neg<Q>(p.y);
+        xyzz_add_affine<Cv>(acc, p);
+    }
+    flush(end);
+    if (!wroteA) xyzz_store<Cv>(partA + (size_t)t * XZ, XYZZ<Cv>::identity());
+    if (!wroteB) xyzz_store<Cv>(partB + (size_t)t * XZ, XYZZ<Cv>::identity());
+}
+
+// buckets spanning >= 2 slices: sum their pieces
+template <class Cv>
+__global__ __launch_bounds__(128) void k_msm_fixup(const uint32_t* __restrict__ off, uint32_t B, uint32_t L,
+                                                   const uint32_t* __restrict__ partA,
+                                                   const uint32_t* __restrict__ partB,
+                                                   uint32_t* __restrict__ buckets) {
+    constexpr int XZ = 4 * Cv::Fq::N;
+    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    uint32_t s = off[b], e = off[b + 1];
+    if (e <= s) return;
+    uint32_t t1 = s / L, t2 = (e - 1) / L;
+    if (t1 == t2) return;
+    XYZZ<Cv> acc = xyzz_load<Cv>(((s % L == 0) ? partA : partB) + (size_t)t1 * XZ);
+    for (uint32_t t = t1 + 1; t <= t2; t++) {
+        XYZZ<Cv> q = xyzz_load<Cv>(partA + (size_t)t * XZ);
+        xyzz_add<Cv>(acc, q);
+    }
+    xyzz_store<Cv>(buckets + (size_t)b * XZ, acc);
+}
+
+// k * p for a small non-negative integer k (double-and-add, MSB first)
+template <class Cv>
+JF_DEV XYZZ<Cv> xyzz_mul_small(const XYZZ<Cv>& p, uint32_t k) {
+    XYZZ<Cv> r = XYZZ<Cv>::identity();
+    for (int bit = 31 - __clz(k | 1u); bit >= 0; bit--) {
+        r = xyzz_double<Cv>(r);
+        if ((k >> bit) & 1u) xyzz_add<Cv>(r, p);
+    }
+    return r;
+}
+
+// lane t folds buckets [t*g, (t+1)*g): V_t = sum_j (t*g + j + 1) * B[t*g + j]
+template <class Cv>
+__global__ __launch_bounds__(64) void k_msm_bucket_fold(const uint32_t* __restrict__ buckets, uint32_t B, uint32_t g,
+                                                        uint32_t* __restrict__ out) {
+    constexpr int XZ = 4 * Cv::Fq::N;
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if ((uint64_t)t * g >= B) return;
+    uint32_t lo = t * g, hi = (lo + g < B) ? lo + g : B;
+    XYZZ<Cv> run = XYZZ<Cv>::identity(), sum = XYZZ<Cv>::identity();
+    for (uint32_t j = hi; j-- > lo;) {
+        XYZZ<Cv> q = xyzz_load<Cv>(buckets + (size_t)j * XZ);
+        xyzz_add<Cv>(run, q);
+        xyzz_add<Cv>(sum, run);
+    }
+    if (lo) {
+        XYZZ<Cv> sh = xyzz_mul_small<Cv>(run, lo);
+        xyzz_add<Cv>(sum, sh);
+    }
+    xyzz_store<Cv>(out + (size_t)t * XZ, sum);
+}
+
+// out[block] = sum of in[block*256*K ...): K serial loads per lane, then an LDS tree
+template <class Cv>
+__global__ __launch_bounds__(256) void k_g1_sum(const uint32_t* __restrict__ in, uint32_t m, uint32_t per_lane,
+                                                uint32_t* __restrict__ out) {
+    constexpr int XZ = 4 * Cv::Fq::N;
+    __shared__ uint32_t sh[256 * XZ];
+    uint32_t base = blockIdx.x * 256u * per_lane;
+    XYZZ<Cv> acc = XYZZ<Cv>::identity();
+    for (uint32_t k = 0; k < per_lane; k++) {
+        uint32_t idx = base + k * 256u + threadIdx.x;
+        if (idx < m) {
+            XYZZ<Cv> q = xyzz_load<Cv>(in + (size_t)idx * XZ);
+            xyzz_add<Cv>(acc, q);
+        }
+    }
+    xyzz_store<Cv>(sh + threadIdx.x * XZ, acc);
+    __syncthreads();
+    for (uint32_t s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            XYZZ<Cv> q = xyzz_load<Cv>(sh + (threadIdx.x + s) * XZ);
+            xyzz_add<Cv>(acc, q);
+            xyzz_store<Cv>(sh + threadIdx.x * XZ, acc);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) xyzz_store<Cv>(out + (size_t)blockIdx.x * XZ, acc);
+}
+
+// XYZZ -> packed affine + u32 infinity flag
+template <class Cv>
+__global__ void k_g1_to_affine(const uint32_t* __restrict__ in, uint32_t* __restrict__ out) {
+    constexpr int PT = 2 * Cv::Fq::N;
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    XYZZ<Cv> p = xyzz_load<Cv>(in);
+    Affine<Cv> a = xyzz_to_affine<Cv>(p);
+    affine_store<Cv>(out, a);
+    out[PT] = p.is_inf() ? 1u : 0u;
+}
+
+template <class Cv>
+__global__ void k_g1_set_identity(uint32_t* __restrict__ out) {
+    constexpr int XZ = 4 * Cv::Fq::N;
+    if (threadIdx.x < XZ && blockIdx.x == 0) out[threadIdx.x] = 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// SRS: packing, window-multiple table, test-SRS generation
+// ------------------------------------------------------------------------------------------
+
+// strided host records (x, y[, infinity byte]) -> packed affine, identity = zeros
+template <class Cv>
+__global__ __launch_bounds__(256) void k_srs_pack(const uint8_t* __restrict__ raw, uint32_t n, uint32_t stride,
+                                                  uint32_t* __restrict__ out) {
+    constexpr int PT = 2 * Cv::Fq::N;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t* rec = raw + (size_t)i * stride;
+    bool inf = (stride > PT * 4u) && rec[PT * 4] != 0;
+    for (int k = 0; k < PT; k++) {
+        uint32_t v;
+        memcpy(&v, rec + 4 * k, 4);
+        out[(size_t)i * PT + k] = inf ? 0u : v;
+    }
+}
+
+template <class Q>
+struct Jac {
+    Fp<Q> X, Y, Z;
+};
+// Jacobian doubling, a = 0 (EFD dbl-2009-l)
+template <class Q>
+JF_DEV Jac<Q> jac_double(const Jac<Q>& p) {
+    Jac<Q> r;
+    auto A = fp_sqr<Q>(p.X);
+    auto Bv = fp_sqr<Q>(p.Y);
+    auto Cc = fp_sqr<Q>(Bv);
+    auto t = fp_add<Q>(p.X, Bv);
+    auto D = fp_dbl<Q>(fp_sub<Q>(fp_sub<Q>(fp_sqr<Q>(t), A), Cc));
+    auto E = fp_add<Q>(fp_dbl<Q>(A), A);
+    auto F = fp_sqr<Q>(E);
+    r.X = fp_sub<Q>(F, fp_dbl<Q>(D));
+    auto C8 = fp_dbl<Q>(fp_dbl<Q>(fp_dbl<Q>(Cc)));
+    r.Y = fp_sub<Q>(fp_mul<Q>(E, fp_sub<Q>(D, r.X)), C8);
+    r.Z = fp_dbl<Q>(fp_mul<Q>(p.Y, p.Z));
+    return r;
+}
+
+// table[w][i] = 2^(c*w) * P_i for points [i0, i0 + m).  One lane per point: Jacobian doubling
+// chain, then Montgomery's trick over the lane's own W-1 denominators (zs / pre are scratch).
+template <class Cv>
+__global__ __launch_bounds__(128) void k_srs_table(uint32_t* __restrict__ table, uint32_t n, uint32_t i0, uint32_t m,
+                                                   int c, int W, uint32_t* __restrict__ zs,
+                                                   uint32_t* __restrict__ pre) {
+    using Q = typename Cv::Fq;
+    constexpr int NQ = Q::N, PT = 2 * Q::N;
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= m) return;
+    uint32_t i = i0 + k;
+    Affine<Cv> p = affine_load<Cv>(table + (size_t)i * PT);
+    if (p.is_inf()) {
+        for (int w = 1; w < W; w++) affine_store<Cv>(table + ((size_t)w * n + i) * PT, p);
+        return;
+    }
+    Jac<Q> J;
+    J.X = p.x;
+    J.Y = p.y;
+    J.Z = Fp<Q>::one();
+    Fp<Q> prod = Fp<Q>::one();
+    for (int w = 1; w < W; w++) {
+        for (int d = 0; d < c; d++) J = jac_double<Q>(J);
+        bool inf = J.Z.is_zero();
+        Fp<Q> zeff = inf ? Fp<Q>::one() : J.Z;
+        Affine<Cv> tmp;
+        tmp.x = inf ? Fp<Q>::zero() : J.X;
+        tmp.y = inf ? Fp<Q>::zero() : J.Y;
+        affine_store<Cv>(table + ((size_t)w * n + i) * PT, tmp);
+        fp_store<Q>(zs + ((size_t)(w - 1) * m + k) * NQ, zeff);
+        fp_store<Q>(pre + ((size_t)(w - 1) * m + k) * NQ, prod);
+        prod = fp_mul<Q>(prod, zeff);
+    }
+    Fp<Q> inv = fp_inv<Q>(prod);
+    for (int w = W - 1; w >= 1; w--) {
+        Fp<Q> z = fp_load<Q>(zs + ((size_t)(w - 1) * m + k) * NQ);
+        Fp<Q> pr = fp_load<Q>(pre + ((size_t)(w - 1) * m + k) * NQ);
+        Fp<Q> zi = fp_mul<Q>(inv, pr);
+        inv = fp_mul<Q>(inv, z);
+        Fp<Q> zi2 = fp_sqr<Q>(zi);
+        uint32_t* slot = table + ((size_t)w * n + i) * PT;
+        Affine<Cv> a = affine_load<Cv>(slot);
+        a.x = fp_mul<Q>(a.x, zi2);
+        a.y = fp_mul<Q>(a.y, fp_mul<Q>(zi2, zi));
+        affine_store<Cv>(slot, a);
+    }
+}
+
+// fixed-base table for test-SRS generation: fb[w][d] = d * 2^(8w) * g, w < 32, d < 256
+template <class Cv>
+__global__ __launch_bounds__(64) void k_fixed_base_table(const uint32_t* __restrict__ g, uint32_t* __restrict__ fb) {
+    using Q = typename Cv::Fq;
+    constexpr int PT = 2 * Q::N;
+    uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= 32 * 256) return;
+    uint32_t w = id >> 8, d = id & 255;
+    Affine<Cv> base = affine_load<Cv>(g);
+    XYZZ<Cv> acc = XYZZ<Cv>::identity();
+    if (d != 0 && !base.is_inf()) {
+        // acc = d * g, then 8w doublings
+        XYZZ<Cv> bp = xyzz_from_affine<Cv>(base);
+        acc = xyzz_mul_small<Cv>(bp, d);
+        for (uint32_t k = 0; k < 8 * w; k++) acc = xyzz_double<Cv>(acc);
+    }
+    affine_store<Cv>(fb + (size_t)id * PT, xyzz_to_affine<Cv>(acc));
+}
+
+// out[i] = [beta^i] g  (gen_srs_for_testing, reference pcs/src/univariate_kzg/srs.rs:175-225)
+template <class Cv>
+__global__ __launch_bounds__(128) void k_srs_gen(const uint32_t* __restrict__ beta, const uint32_t* __restrict__ fb,
+                                                 uint32_t n, uint32_t* __restrict__ out) {
+    using Q = typename Cv::Fq;
+    using Fr = typename Cv::Fr;
+    constexpr int PT = 2 * Q::N;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fp<Fr> s = fp_from_mont<Fr>(fp_pow_u64<Fr>(fp_load<Fr>(beta), i));
+    XYZZ<Cv> acc = XYZZ<Cv>::identity();
+    for (int w = 0; w < 32; w++) {
+        uint32_t d = extract_bits<Fr::N>(s.v, 8 * w, 8);
+        if (d) {
+            Affine<Cv> p = affine_load<Cv>(fb + (size_t)(w * 256 + d) * PT);
+            xyzz_add_affine<Cv>(acc, p);
+        }
+    }
+    affine_store<Cv>(out + (size_t)i * PT, xyzz_to_affine<Cv>(acc));
+}
+
+// ---- small group ops for the test surface ---------------------------------------------------
+template <class Cv>
+__global__ void k_g1_op(int op, const uint32_t* __restrict__ P, const uint32_t* __restrict__ Qp,
+                        uint32_t* __restrict__ out) {
+    using Fr = typename Cv::Fr;
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    Affine<Cv> p = affine_load<Cv>(P);
+    XYZZ<Cv> acc = xyzz_from_affine<Cv>(p);
+    if (op == 0) {
+        Affine<Cv> q = affine_load<Cv>(Qp);
+        xyzz_add_affine<Cv>(acc, q);
+    } else {
+        Fp<Fr> k = fp_from_mont<Fr>(fp_load<Fr>(Qp));
+        XYZZ<Cv> r = XYZZ<Cv>::identity();
+        for (int bit = 32 * Fr::N - 1; bit >= 0; bit--) {
+            r = xyzz_double<Cv>(r);
+            if (extract_bits<Fr::N>(k.v, bit, 1)) xyzz_add<Cv>(r, acc);
+        }
+        acc = r;
+    }
+    affine_store<Cv>(out, xyzz_to_affine<Cv>(acc));
+}
+
+// ------------------------------------------------------------------------------------------
+// host drivers
+// ------------------------------------------------------------------------------------------
+
+int windows_for(int32_t curve, int c) {
+    int bits = (curve == JFHIP_BN254 ? 254 : 255) + 1;  // +1: signed-digit carry
+    return (bits + c - 1) / c;
+}
+
+int choose_window_bits(int32_t curve, size_t n) {
+    // minimise n * W(c) * 10 + 2^(c-1) * 60 field multiplications (accumulate + fold)
+    int best = 8;
+    double best_cost = 1e300;
+    for (int c = 6; c <= 23; c++) {
+        int W = windows_for(curve, c);
+        if ((double)W * (double)n >= 2147483648.0) continue;
+        double cost = (double)n * W * 10.0 + (double)(1u << (c - 1)) * 60.0;
+        if (cost < best_cost) {
+            best_cost = cost;
+            best = c;
+        }
+    }
+    return best;
+}
+
+template <class Cv>
+static int32_t srs_build_table_t(jfhip_srs* srs, jfhip_stream* st) {
+    constexpr int NQ = Cv::Fq::N;
+    const size_t n = srs->n;
+    if (srs->W <= 1) return JFHIP_OK;
+    const size_t tile = n < ((size_t)1 << 20) ? n : ((size_t)1 << 20);
+    DevBuf zs, pre;
+    JF_TRY(zs.ensure((size_t)(srs->W - 1) * tile * NQ * 4));
+    JF_TRY(pre.ensure((size_t)(srs->W - 1) * tile * NQ * 4));
+    for (size_t i0 = 0; i0 < n; i0 += tile) {
+        uint32_t m = (uint32_t)((n - i0 < tile) ? n - i0 : tile);
+        hipLaunchKernelGGL((k_srs_table<Cv>), dim3((m + 127) / 128), dim3(128), 0, st->s, srs->table, (uint32_t)n,
+                           (uint32_t)i0, m, srs->c, srs->W, zs.as<uint32_t>(), pre.as<uint32_t>());
+    }
+    JF_HIP(hipGetLastError());
+    JF_HIP(hipStreamSynchronize(st->s));
+    zs.release();
+    pre.release();
+    return JFHIP_OK;
+}
+
+int32_t srs_build_table(jfhip_srs* srs, const uint32_t* d_points_packed, jfhip_stream* st) {
+    const int PT = 2 * fq_limbs32(srs->curve);
+    if (d_points_packed != srs->table)
+        JF_HIP(hipMemcpyAsync(srs->table, d_points_packed, srs->n * PT * 4, hipMemcpyDeviceToDevice, st->s));
+    if (srs->curve == JFHIP_BN254) return srs_build_table_t<Bn254G1>(srs, st);
+    return srs_build_table_t<Bls381G1>(srs, st);
+}
+
+int32_t srs_pack_points(int32_t curve, const uint8_t* d_raw, size_t n, size_t stride, uint32_t* d_out,
+                        jfhip_stream* st) {
+    dim3 grid((unsigned)((n + 255) / 256));
+    if (curve == JFHIP_BN254)
+        hipLaunchKernelGGL((k_srs_pack<Bn254G1>), grid, dim3(256), 0, st->s, d_raw, (uint32_t)n, (uint32_t)stride,
+                           d_out);
+    else
+        hipLaunchKernelGGL((k_srs_pack<Bls381G1>), grid, dim3(256), 0, st->s, d_raw, (uint32_t)n, (uint32_t)stride,
+                           d_out);
+    JF_HIP(hipGetLastError());
+    return JFHIP_OK;
+}
+
+template <class Cv>
+static int32_t srs_gen_t(const uint64_t* beta_mont, const uint64_t* g_xy, size_t n, uint32_t* d_out,
+                         jfhip_stream* st) {
+    constexpr int PT = 2 * Cv::Fq::N;
+    DevBuf par, fb;
+    JF_TRY(par.ensure((8 + PT) * 4));
+    JF_TRY(fb.ensure((size_t)32 * 256 * PT * 4));
+    JF_HIP(hipMemcpyAsync(par.p, beta_mont, 32, hipMemcpyHostToDevice, st->s));
+    JF_HIP(hipMemcpyAsync(par.as<uint32_t>() + 8, g_xy, PT * 4, hipMemcpyHostToDevice, st->s));
+    hipLaunchKernelGGL((k_fixed_base_table<Cv>), dim3(32 * 256 / 64), dim3(64), 0, st->s, par.as<uint32_t>() + 8,
+                       fb.as<uint32_t>());
+    hipLaunchKernelGGL((k_srs_gen<Cv>), dim3((unsigned)((n + 127) / 128)), dim3(128), 0, st->s, par.as<uint32_t>(),
+                       fb.as<uint32_t>(), (uint32_t)n, d_out);
+    JF_HIP(hipGetLastError());
+    JF_HIP(hipStreamSynchronize(st->s));
+    par.release();
+    fb.release();
+    return JFHIP_OK;
+}
+
+int32_t srs_gen_points(int32_t curve, const uint64_t* beta_mont, const uint64_t* g_xy, size_t n, uint32_t* d_out,
+                       jfhip_stream* st) {
+    if (curve == JFHIP_BN254) return srs_gen_t<Bn254G1>(beta_mont, g_xy, n, d_out, st);
+    return srs_gen_t<Bls381G1>(beta_mont, g_xy, n, d_out, st);
+}
+
+template <class Cv>
+static int32_t g1_sum_xyzz_t(const uint32_t* d_in, size_t count, uint32_t* d_out_xyzz, jfhip_stream* st) {
+    // tree of k_g1_sum launches, ping-ponging between red0 / red1; final point -> d_out_xyzz
+    constexpr int XZ = 4 * Cv::Fq::N;
+    if (count == 0) {
+        hipLaunchKernelGGL((k_g1_set_identity<Cv>), dim3(1), dim3(64), 0, st->s, d_out_xyzz);
+        JF_HIP(hipGetLastError());
+        return JFHIP_OK;
+    }
+    const uint32_t* cur = d_in;
+    size_t m = count;
+    int flip = 0;
+    for (;;) {
+        uint32_t per_lane = m > 65536 ? 4 : 1;
+        size_t blocks = (m + 256 * per_lane - 1) / (256 * per_lane);
+        uint32_t* dst;
+        if (blocks == 1) dst = d_out_xyzz;
+        else {
+            DevBuf& buf = flip ? st->red1 : st->red0;
+            JF_TRY(buf.ensure(blocks * XZ * 4));
+            dst = buf.as<uint32_t>();
+        }
+        hipLaunchKernelGGL((k_g1_sum<Cv>), dim3((unsigned)blocks), dim3(256), 0, st->s, cur, (uint32_t)m, per_lane,
+                           dst);
+        JF_HIP(hipGetLastError());
+        if (blocks == 1) break;
+        cur = dst;
+        m = blocks;
+        flip ^= 1;
+    }
+    return JFHIP_OK;
+}
+
+template <class Cv>
+static int32_t msm_partial_t(const jfhip_srs* srs, size_t offset, const uint32_t* d_scalars, size_t n,
+                             uint32_t* d_out_xyzz, jfhip_stream* st) {
+    constexpr int XZ = 4 * Cv::Fq::N;
+    PhaseTimer pt(st, 0);
+    if (n == 0) {
+        hipLaunchKernelGGL((k_g1_set_identity<Cv>), dim3(1), dim3(64), 0, st->s, d_out_xyzz);
+        JF_HIP(hipGetLastError());
+        pt.finish();
+        return JFHIP_OK;
+    }
+    const int c = srs->c, W = srs->W;
+    const uint32_t B = 1u << (c - 1);
+    const size_t total_max = n * (size_t)W;
+    if (total_max >= ((size_t)1 << 32)) {
+        set_error("msm too large: n * windows = %zu exceeds 2^32", total_max);
+        return JFHIP_ERR_INVALID;
+    }
+    // slice length: enough lanes to fill 256 CUs x 4 SIMDs x ~4 waves, at most 256 entries per lane
+    size_t L = (total_max + 262143) / 262144;
+    if (L < 16) L = 16;
+    if (L > 256) L = 256;
+    const size_t T = (total_max + L - 1) / L;
+    const uint32_t nblk = (B + SCAN_BLOCK * SCAN_ITEMS - 1) / (SCAN_BLOCK * SCAN_ITEMS);
+
+    JF_TRY(st->dig.ensure(total_max * 4));
+    JF_TRY(st->sorted.ensure(total_max * 4));
+    JF_TRY(st->counts.ensure((size_t)B * 4));
+    JF_TRY(st->offs.ensure(((size_t)B + 1) * 4));
+    JF_TRY(st->cursor.ensure((size_t)B * 4));
+    JF_TRY(st->bsum.ensure((size_t)nblk * 4));
+    JF_TRY(st->buckets.ensure((size_t)B * XZ * 4));
+    // fold: g buckets per lane, then a sum tree (the fold output reuses partA after the fix-up)
+    uint32_t g = 16;
+    if (B < 4096) g = 4;
+    const uint32_t Tf = (B + g - 1) / g;
+    JF_TRY(st->partA.ensure((T > Tf ? T : Tf) * XZ * 4));
+    JF_TRY(st->partB.ensure(T * XZ * 4));
+
+    uint32_t* counts = st->counts.as<uint32_t>();
+    uint32_t* offs = st->offs.as<uint32_t>();
+    uint32_t* cursor = st->cursor.as<uint32_t>();
+    uint32_t* bsum = st->bsum.as<uint32_t>();
+    uint32_t* buckets = st->buckets.as<uint32_t>();
+
+    JF_HIP(hipMemsetAsync(counts, 0, (size_t)B * 4, st->s));
+    JF_HIP(hipMemsetAsync(buckets, 0, (size_t)B * XZ * 4, st->s));
+    hipLaunchKernelGGL((k_msm_digits<Cv>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st->s, d_scalars,
+                       (uint32_t)n, c, W, st->dig.as<int32_t>(), counts);
+    pt.mark();
+    hipLaunchKernelGGL(k_scan_local, dim3(nblk), dim3(SCAN_BLOCK), 0, st->s, counts, B, offs, bsum);
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(SCAN_BLOCK), 0, st->s, bsum, nblk, offs + B);
+    hipLaunchKernelGGL(k_scan_add, dim3((B + 255) / 256), dim3(256), 0, st->s, offs, B, bsum, cursor);
+    hipLaunchKernelGGL(k_msm_scatter, dim3((unsigned)((total_max + 255) / 256)), dim3(256), 0, st->s,
+                       st->dig.as<int32_t>(), (uint32_t)n, W, (uint32_t)srs->n, (uint32_t)offset, cursor,
+                       st->sorted.as<uint32_t>());
+    pt.mark();
+    hipLaunchKernelGGL((k_msm_accumulate<Cv>), dim3((unsigned)((T + 127) / 128)), dim3(128), 0, st->s,
+                       st->sorted.as<uint32_t>(), offs, B, srs->table, (uint32_t)L, buckets,
+                       st->partA.as<uint32_t>(), st->partB.as<uint32_t>());
+    pt.mark();
+    hipLaunchKernelGGL((k_msm_fixup<Cv>), dim3((B + 127) / 128), dim3(128), 0, st->s, offs, B, (uint32_t)L,
+                       st->partA.as<uint32_t>(), st->partB.as<uint32_t>(), buckets);
+    pt.mark();
+    DevBuf& fold = st->partA;  // partA is free again after the fix-up
+    hipLaunchKernelGGL((k_msm_bucket_fold<Cv>), dim3((Tf + 63) / 64), dim3(64), 0, st->s, buckets, B, g,
+                       fold.as<uint32_t>());
+    JF_HIP(hipGetLastError());
+    pt.mark();
+    JF_TRY(g1_sum_xyzz_t<Cv>(fold.as<uint32_t>(), Tf, d_out_xyzz, st));
+    pt.mark();
+    pt.finish();
+    return JFHIP_OK;
+}
+
+int32_t msm_partial_device(const jfhip_srs* srs, size_t offset, const uint32_t* d_scalars, size_t n,
+                           uint32_t* d_out_xyzz, jfhip_stream* st) {
+    if (srs->curve == JFHIP_BN254) return msm_partial_t<Bn254G1>(srs, offset, d_scalars, n, d_out_xyzz, st);
+    return msm_partial_t<Bls381G1>(srs, offset, d_scalars, n, d_out_xyzz, st);
+}
+
+template <class Cv>
+static int32_t g1_sum_to_affine_t(const uint32_t* d_partials, size_t count, uint32_t* d_out, jfhip_stream* st) {
+    constexpr int XZ = 4 * Cv::Fq::N;
+    JF_TRY(st->result.ensure(XZ * 4));
+    const uint32_t* src = d_partials;
+    if (count != 1) {
+        JF_TRY(g1_sum_xyzz_t<Cv>(d_partials, count, st->result.as<uint32_t>(), st));
+        src = st->result.as<uint32_t>();
+    }
+    hipLaunchKernelGGL((k_g1_to_affine<Cv>), dim3(1), dim3(64), 0, st->s, src, d_out);
+    JF_HIP(hipGetLastError());
+    return JFHIP_OK;
+}
+
+int32_t g1_sum_to_affine(int32_t curve, const uint32_t* d_partials, size_t count, uint32_t* d_out,
+                         jfhip_stream* st) {
+    if (curve == JFHIP_BN254) return g1_sum_to_affine_t<Bn254G1>(d_partials, count, d_out, st);
+    return g1_sum_to_affine_t<Bls381G1>(d_partials, count, d_out, st);
+}
+
+int32_t g1_op_device(int32_t curve, int32_t op, const uint32_t* P, const uint32_t* Q, uint32_t* out, hipStream_t s) {
+    if (curve == JFHIP_BN254) hipLaunchKernelGGL((k_g1_op<Bn254G1>), dim3(1), dim3(64), 0, s, op, P, Q, out);
+    else hipLaunchKernelGGL((k_g1_op<Bls381G1>), dim3(1), dim3(64), 0, s, op, P, Q, out);
+    JF_HIP(hipGetLastError());
+    return JFHIP_OK;
+}
+
+}  // namespace jf

@@ -1,0 +1,399 @@
+// Radix-2 (coset) NTT / iNTT over Fr for gfx950: the transforms jf-plonk's prover runs through
+// ark-poly's Radix2EvaluationDomain (reference call sites plonk/src/proof_system/prover.rs:
+// 534-573,658-660 and relation/src/constraint_system.rs:1369-1622).
+//
+// Semantics: natural order in and out,
+//   forward  out[i] = sum_j in[j] (h w^i)^j,  inverse = exact inverse (n^-1, h^-j scaling),
+//   w = TWO_ADIC_ROOT_OF_UNITY^(2^(s - log n)), input zero-extended from in_len.
+//
+// Structure: mixed-radix Cooley-Tukey over P = ceil(log n / 8) digit passes.  A pass loads a
+// tile of 2048 elements (2^d-point transforms x 2048/2^d adjacent columns) into LDS with
+// coalesced 32-byte-per-lane rows, runs d butterfly layers out of LDS, applies the inter-pass
+// twiddle (two-level table, so no n-sized twiddle array is streamed from HBM) and stores.
+// The last pass performs the digit-reversal as a transposed store whose inner run is the
+// first digit, so stores stay in 2^d-element-aligned contiguous segments.  The coset
+// pre-scale / inverse post-scale are fused into the first load / last store.
+#include <map>
+#include <mutex>
+
+#include "common.hpp"
+#include "fp.hpp"
+
+namespace jf {
+
+constexpr int NTT_TILE_LOG = 11;  // 2048 elements x 32 B = 64 KiB of LDS
+constexpr int NTT_TILE = 1 << NTT_TILE_LOG;
+constexpr int NTT_MAX_DIGIT = 8;
+constexpr int NTT_THREADS = 256;
+
+struct NttTables {
+    uint32_t* params = nullptr;    // [0] w_n  [1] w_256  [2] n^-1  [3] h (or h^-1)   (8 limbs each)
+    uint32_t* tw_small = nullptr;  // w_256^k, k < 128
+    uint32_t* tl = nullptr;        // w_n^i, i < 2^a
+    uint32_t* th = nullptr;        // w_n^(i 2^a), i < 2^(log_n - a)
+    uint32_t* cl = nullptr;        // h^i
+    uint32_t* ch = nullptr;        // s0 * h^(i 2^a)
+    uint32_t a = 0;
+    int scale_mode = 0;  // 0 none, 1 constant n^-1, 2 two-level table
+};
+
+struct NttPass {
+    const uint32_t* src;
+    uint32_t* dst;
+    uint32_t log_n, batch, dbits, log_M, in_len;
+    int first, final, inverse;
+    uint32_t ndig;
+    uint32_t dig[4];
+    NttTables t;
+};
+
+JF_DEV uint32_t bitrev_n(uint32_t x, uint32_t bits) { return bits ? (__brev(x) >> (32 - bits)) : 0u; }
+
+// lo[e mod 2^a] * hi[e >> a]; hi[0] is 1 unless the table carries a scale (ALWAYS_HI)
+template <class Fr, bool ALWAYS_HI = false>
+JF_DEV Fp<Fr> two_level(const uint32_t* __restrict__ lo, const uint32_t* __restrict__ hi, uint32_t a, uint64_t e) {
+    Fp<Fr> x = fp_load<Fr>(lo + (size_t)(e & ((1ull << a) - 1)) * Fr::N);
+    uint64_t h = e >> a;
+    if (ALWAYS_HI || h) x = fp_mul<Fr>(x, fp_load<Fr>(hi + (size_t)h * Fr::N));
+    return x;
+}
+
+template <class Fr>
+__global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPass P) {
+    constexpr int N = Fr::N;
+    __shared__ uint32_t lds[NTT_TILE * N + 128 * N];
+    uint32_t* tws = lds + NTT_TILE * N;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t d = P.dbits;
+    const uint32_t logC = NTT_TILE_LOG - d;
+    const uint32_t C = 1u << logC;
+    const uint64_t ncols = (uint64_t)P.batch << (P.log_n - d);
+    const uint64_t g0 = (uint64_t)blockIdx.x << logC;
+    const uint32_t log_S = P.log_M - d;                 // stride of this digit inside its row
+    const uint32_t log_rows = P.log_n - P.log_M;        // rows of length M per polynomial
+    const uint64_t n = 1ull << P.log_n;
+
+    if (tid < 128) {
+        Fp<Fr> w = fp_load<Fr>(P.t.tw_small + tid * N);
+        fp_store<Fr>(tws + tid * N, w);
+    }
+
+    // column -> (poly, base element index inside the poly) for non-final passes
+    auto col_base = [&](uint64_t g, uint32_t& poly, uint64_t& base, uint32_t& jrest) {
+        jrest = (uint32_t)(g & ((1ull << log_S) - 1));
+        uint64_t row = (g >> log_S) & ((1ull << log_rows) - 1);
+        poly = (uint32_t)(g >> (log_S + log_rows));
+        base = (row << P.log_M) + jrest;
+    };
+    // final pass: columns are rows of 2^d contiguous elements, enumerated with the first digit fastest
+    const uint32_t R1bits = (P.ndig >= 2) ? P.dig[0] : 0;
+    const uint32_t log_NR = P.log_n - d;  // rows per polynomial
+    auto final_col = [&](uint64_t g, uint32_t& poly, uint64_t& row, uint64_t& outbase) {
+        uint32_t k1 = (uint32_t)(g & ((1ull << R1bits) - 1));
+        uint64_t rest = (g >> R1bits) & ((1ull << (log_NR - R1bits)) - 1);
+        poly = (uint32_t)(g >> log_NR);
+        row = ((uint64_t)k1 << (log_NR - R1bits)) + rest;
+        // digit-reverse `rest` (digits 2..ndig-1, the earliest digit outermost)
+        uint64_t rev = 0;
+        uint32_t shift = 0, consumed = 0;
+        uint32_t rest_bits = log_NR - R1bits;
+        for (uint32_t q = 1; q + 1 < P.ndig; q++) {
+            uint32_t bq = P.dig[q];
+            consumed += bq;
+            uint64_t kq = (rest >> (rest_bits - consumed)) & ((1ull << bq) - 1);
+            rev |= kq << shift;
+            shift += bq;
+        }
+        outbase = k1 + (rev << R1bits);
+    };
+
+    // ---- load (bit-reversed along the transform axis) -----------------------------------
+#pragma unroll 2
+    for (int it = 0; it < NTT_TILE / NTT_THREADS; it++) {
+        uint32_t e = it * NTT_THREADS + tid;
+        uint32_t col = e & (C - 1), jp = e >> logC;
+        uint64_t g = g0 + col;
+        Fp<Fr> x = Fp<Fr>::zero();
+        if (g < ncols) {
+            uint32_t poly;
+            uint64_t idx;
+            if (!P.final || P.first) {
+                // (a single-pass transform is both first and final: plain row addressing)
+                uint64_t base;
+                uint32_t jrest;
+                if (P.final) {
+                    poly = (uint32_t)g;
+                    base = 0;
+                } else col_base(g, poly, base, jrest);
+                idx = base + ((uint64_t)jp << log_S);
+            } else {
+                uint64_t row, ob;
+                final_col(g, poly, row, ob);
+                idx = (row << d) + jp;
+            }
+            if (!P.first || idx < P.in_len) {
+                x = fp_load<Fr>(P.src + ((size_t)poly * n + idx) * N);
+                if (P.first && !P.inverse && P.t.scale_mode == 2 && idx)
+                    x = fp_mul<Fr>(x, two_level<Fr>(P.t.cl, P.t.ch, P.t.a, idx));
+            }
+        }
+        fp_store<Fr>(lds + (((size_t)bitrev_n(jp, d) << logC) + col) * N, x);
+    }
+    __syncthreads();
+
+    // ---- d butterfly layers (decimation in time) --------------------------------------------
+    for (uint32_t s = 1; s <= d; s++) {
+        const uint32_t log_half = s - 1, half = 1u << log_half;
+#pragma unroll 2
+        for (int it = 0; it < NTT_TILE / 2 / NTT_THREADS; it++) {
+            uint32_t bf = it * NTT_THREADS + tid;
+            uint32_t col = bf & (C - 1), q = bf >> logC;
+            uint32_t j = q & (half - 1), grp = q >> log_half;
+            uint32_t i0 = (grp << s) + j, i1 = i0 + half;
+            uint32_t* p0 = lds + (((size_t)i0 << logC) + col) * N;
+            uint32_t* p1 = lds + (((size_t)i1 << logC) + col) * N;
+            Fp<Fr> u = fp_load<Fr>(p0), v = fp_load<Fr>(p1);
+            if (j) v = fp_mul<Fr>(v, fp_load<Fr>(tws + (size_t)(j << (7 - log_half)) * N));
+            fp_store<Fr>(p0, fp_add<Fr>(u, v));
+            fp_store<Fr>(p1, fp_sub<Fr>(u, v));
+        }
+        __syncthreads();
+    }
+
+    // ---- store ----------------------------------------------------------------------------------
+#pragma unroll 2
+    for (int it = 0; it < NTT_TILE / NTT_THREADS; it++) {
+        uint32_t e = it * NTT_THREADS + tid;
+        uint32_t col = e & (C - 1), k = e >> logC;
+        uint64_t g = g0 + col;
+        if (g >= ncols) continue;
+        Fp<Fr> x = fp_load<Fr>(lds + (((size_t)k << logC) + col) * N);
+        uint32_t poly;
+        uint64_t pos;
+        if (!P.final) {
+            uint64_t base;
+            uint32_t jrest;
+            col_base(g, poly, base, jrest);
+            pos = base + ((uint64_t)k << log_S);
+            uint64_t E = ((uint64_t)k * jrest) << log_rows;  // exponent of w_n
+            if (E) x = fp_mul<Fr>(x, two_level<Fr>(P.t.tl, P.t.th, P.t.a, E));
+        } else {
+            if (P.ndig == 1) {
+                poly = (uint32_t)g;
+                pos = k;
+            } else {
+                uint64_t row, ob;
+                final_col(g, poly, row, ob);
+                pos = ob + ((uint64_t)k << log_NR);
+            }
+            if (P.inverse) {
+                if (P.t.scale_mode == 1) x = fp_mul<Fr>(x, fp_load<Fr>(P.t.params + 2 * N));
+                else if (P.t.scale_mode == 2) x = fp_mul<Fr>(x, two_level<Fr, true>(P.t.cl, P.t.ch, P.t.a, pos));
+            }
+        }
+        fp_store<Fr>(P.dst + ((size_t)poly * n + pos) * N, x);
+    }
+}
+
+// ---- table construction ----------------------------------------------------------------------
+template <class Fr>
+struct RootConst;
+template <>
+struct RootConst<Bn254Fr> {
+    static constexpr int TWO_ADICITY = 28;
+    JF_HD static constexpr uint32_t ROOT(int i) {  // Fr::TWO_ADIC_ROOT_OF_UNITY, canonical integer
+        constexpr uint32_t v[8] = {0x725b19f0u, 0x9bd61b6eu, 0x41112ed4u, 0x402d111eu,
+                                   0x8ef62abcu, 0x00e0a7ebu, 0xa58a7e85u, 0x2a3c09f0u};
+        return v[i];
+    }
+};
+template <>
+struct RootConst<Bls381Fr> {
+    static constexpr int TWO_ADICITY = 32;
+    JF_HD static constexpr uint32_t ROOT(int i) {
+        constexpr uint32_t v[8] = {0x439f0d2bu, 0x3829971fu, 0x8c2280b9u, 0xb6368350u,
+                                   0x22c813b4u, 0xd09b6819u, 0xdfe81f20u, 0x16a2a19eu};
+        return v[i];
+    }
+};
+
+// params: [0] w_n^(+-1), [1] w_256^(+-1), [2] n^-1, [3] h^(+-1)
+template <class Fr>
+__global__ void k_ntt_params(uint32_t log_n, int inverse, const uint32_t* __restrict__ coset, int has_coset,
+                             uint32_t* __restrict__ params) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    constexpr int N = Fr::N;
+    Fp<Fr> root;
+    for (int i = 0; i < N; i++) root.v[i] = RootConst<Fr>::ROOT(i);
+    root = fp_to_mont<Fr>(root);
+    Fp<Fr> wn = root, w256 = root;
+    for (uint32_t i = log_n; i < (uint32_t)RootConst<Fr>::TWO_ADICITY; i++) wn = fp_sqr<Fr>(wn);
+    for (uint32_t i = 8; i < (uint32_t)RootConst<Fr>::TWO_ADICITY; i++) w256 = fp_sqr<Fr>(w256);
+    Fp<Fr> h = has_coset ? fp_load<Fr>(coset) : Fp<Fr>::one();
+    Fp<Fr> ninv = Fp<Fr>::one();
+    if (inverse) {
+        wn = fp_inv<Fr>(wn);
+        w256 = fp_inv<Fr>(w256);
+        h = fp_inv<Fr>(h);
+        // n^-1 = (2^-1)^log_n
+        Fp<Fr> two = fp_dbl<Fr>(Fp<Fr>::one());
+        ninv = fp_pow_u64<Fr>(fp_inv<Fr>(two), log_n);
+    }
+    fp_store<Fr>(params, wn);
+    fp_store<Fr>(params + N, w256);
+    fp_store<Fr>(params + 2 * N, ninv);
+    fp_store<Fr>(params + 3 * N, h);
+}
+
+// out[i] = scale * base^(i * stride)
+template <class Fr>
+__global__ __launch_bounds__(256) void k_pow_table(const uint32_t* __restrict__ base, const uint32_t* __restrict__ scale,
+                                                   uint64_t stride, uint32_t count, uint32_t* __restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    Fp<Fr> v = fp_pow_u64<Fr>(fp_load<Fr>(base), (uint64_t)i * stride);
+    if (scale) v = fp_mul<Fr>(v, fp_load<Fr>(scale));
+    fp_store<Fr>(out + (size_t)i * Fr::N, v);
+}
+
+struct TableKey {
+    int device, curve, inverse, has_coset;
+    uint32_t log_n;
+    uint64_t coset[4];
+    bool operator<(const TableKey& o) const { return memcmp(this, &o, sizeof(TableKey)) < 0; }
+};
+static std::mutex g_tab_mu;
+static std::map<TableKey, NttTables> g_tables;
+
+template <class Fr>
+static int32_t build_tables(uint32_t log_n, int inverse, const uint64_t* coset_mont, NttTables* out,
+                            jfhip_stream* st) {
+    constexpr int N = Fr::N;
+    NttTables t;
+    t.a = (log_n + 1) / 2;
+    const uint32_t lo_n = 1u << t.a, hi_n = 1u << (log_n - t.a);
+    const bool has_coset = coset_mont != nullptr;
+    t.scale_mode = has_coset ? 2 : (inverse ? 1 : 0);
+    uint32_t* d_coset = nullptr;
+    JF_HIP(hipMalloc(&t.params, 4 * N * 4));
+    JF_HIP(hipMalloc(&t.tw_small, 128 * N * 4));
+    JF_HIP(hipMalloc(&t.tl, (size_t)lo_n * N * 4));
+    JF_HIP(hipMalloc(&t.th, (size_t)hi_n * N * 4));
+    if (has_coset) {
+        JF_HIP(hipMalloc(&d_coset, N * 4));
+        JF_HIP(hipMemcpyAsync(d_coset, coset_mont, N * 4, hipMemcpyHostToDevice, st->s));
+        JF_HIP(hipMalloc(&t.cl, (size_t)lo_n * N * 4));
+        JF_HIP(hipMalloc(&t.ch, (size_t)hi_n * N * 4));
+    }
+    hipLaunchKernelGGL((k_ntt_params<Fr>), dim3(1), dim3(64), 0, st->s, log_n, inverse, d_coset, (int)has_coset,
+                       t.params);
+    hipLaunchKernelGGL((k_pow_table<Fr>), dim3(1), dim3(256), 0, st->s, t.params + N, (const uint32_t*)nullptr,
+                       (uint64_t)1, 128u, t.tw_small);
+    hipLaunchKernelGGL((k_pow_table<Fr>), dim3((lo_n + 255) / 256), dim3(256), 0, st->s, t.params,
+                       (const uint32_t*)nullptr, (uint64_t)1, lo_n, t.tl);
+    hipLaunchKernelGGL((k_pow_table<Fr>), dim3((hi_n + 255) / 256), dim3(256), 0, st->s, t.params,
+                       (const uint32_t*)nullptr, (uint64_t)lo_n, hi_n, t.th);
+    if (has_coset) {
+        hipLaunchKernelGGL((k_pow_table<Fr>), dim3((lo_n + 255) / 256), dim3(256), 0, st->s, t.params + 3 * N,
+                           (const uint32_t*)nullptr, (uint64_t)1, lo_n, t.cl);
+        hipLaunchKernelGGL((k_pow_table<Fr>), dim3((hi_n + 255) / 256), dim3(256), 0, st->s, t.params + 3 * N,
+                           inverse ? t.params + 2 * N : (const uint32_t*)nullptr, (uint64_t)lo_n, hi_n, t.ch);
+    }
+    JF_HIP(hipGetLastError());
+    JF_HIP(hipStreamSynchronize(st->s));
+    if (d_coset) JF_HIP(hipFree(d_coset));
+    *out = t;
+    return JFHIP_OK;
+}
+
+template <class Fr>
+static int32_t ntt_device_t(int32_t curve, uint32_t* d_data, uint32_t log_n, size_t batch, int inverse,
+                            const uint64_t* coset_mont, size_t in_len, jfhip_stream* st) {
+    constexpr int N = Fr::N;
+    if (log_n > (uint32_t)RootConst<Fr>::TWO_ADICITY || log_n > 30) {
+        set_error("ntt: log_n %u exceeds the field's two-adicity / supported size", log_n);
+        return JFHIP_ERR_INVALID;
+    }
+    const size_t n = (size_t)1 << log_n;
+    if (in_len == 0 || in_len > n) in_len = n;
+    if (batch == 0) return JFHIP_OK;
+    if ((batch << log_n) >= ((size_t)1 << 40)) {
+        set_error("ntt: batch too large");
+        return JFHIP_ERR_INVALID;
+    }
+    // a trivial coset (h = 1) is the plain domain
+    if (coset_mont) {
+        bool is_one = true;
+        for (int i = 0; i < 4; i++) {
+            uint64_t one = ((uint64_t)Fr::ONE(2 * i + 1) << 32) | Fr::ONE(2 * i);
+            if (coset_mont[i] != one) is_one = false;
+        }
+        if (is_one) coset_mont = nullptr;
+    }
+    if (log_n == 0) {
+        // n = 1: the transform is the identity (h^0 = 1, n^-1 = 1); honour zero-extension only
+        return JFHIP_OK;
+    }
+    PhaseTimer pt(st, 1);
+    NttTables tabs;
+    {
+        TableKey key;
+        memset(&key, 0, sizeof(key));
+        JF_HIP(hipGetDevice(&key.device));
+        key.curve = curve;
+        key.inverse = inverse ? 1 : 0;
+        key.has_coset = coset_mont ? 1 : 0;
+        key.log_n = log_n;
+        if (coset_mont) memcpy(key.coset, coset_mont, 32);
+        std::lock_guard<std::mutex> lk(g_tab_mu);
+        auto it = g_tables.find(key);
+        if (it == g_tables.end()) {
+            JF_TRY(build_tables<Fr>(log_n, inverse ? 1 : 0, coset_mont, &tabs, st));
+            g_tables[key] = tabs;
+        } else tabs = it->second;
+    }
+    // digit plan
+    uint32_t ndig = (log_n + NTT_MAX_DIGIT - 1) / NTT_MAX_DIGIT;
+    uint32_t dig[4] = {0, 0, 0, 0};
+    for (uint32_t p = 0; p < ndig; p++) dig[p] = log_n / ndig + (p < log_n % ndig ? 1 : 0);
+
+    uint32_t* tmp = nullptr;
+    if (ndig >= 2) {
+        JF_TRY(st->ntt_tmp.ensure(batch * n * N * 4));
+        tmp = st->ntt_tmp.as<uint32_t>();
+    }
+    uint32_t log_M = log_n;
+    for (uint32_t p = 0; p < ndig; p++) {
+        NttPass P;
+        P.first = (p == 0);
+        P.final = (p == ndig - 1);
+        P.inverse = inverse ? 1 : 0;
+        P.src = (p == 0) ? d_data : tmp;
+        P.dst = (ndig == 1 || P.final) ? d_data : tmp;
+        P.log_n = log_n;
+        P.batch = (uint32_t)batch;
+        P.dbits = dig[p];
+        P.log_M = log_M;
+        P.in_len = (uint32_t)in_len;
+        P.ndig = ndig;
+        for (int q = 0; q < 4; q++) P.dig[q] = dig[q];
+        P.t = tabs;
+        uint64_t ncols = (uint64_t)batch << (log_n - dig[p]);
+        uint32_t logC = NTT_TILE_LOG - dig[p];
+        uint64_t blocks = (ncols + (1ull << logC) - 1) >> logC;
+        hipLaunchKernelGGL((k_ntt_pass<Fr>), dim3((unsigned)blocks), dim3(NTT_THREADS), 0, st->s, P);
+        JF_HIP(hipGetLastError());
+        pt.mark();
+        log_M -= dig[p];
+    }
+    pt.finish();
+    return JFHIP_OK;
+}
+
+int32_t ntt_device(int32_t curve, uint32_t* d_data, uint32_t log_n, size_t batch, int inverse,
+                   const uint64_t* coset_mont, size_t in_len, jfhip_stream* st) {
+    if (curve == JFHIP_BN254) return ntt_device_t<Bn254Fr>(curve, d_data, log_n, batch, inverse, coset_mont, in_len, st);
+    return ntt_device_t<Bls381Fr>(curve, d_data, log_n, batch, inverse, coset_mont, in_len, st);
+}
+
+}  // namespace jf

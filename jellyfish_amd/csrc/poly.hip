@@ -1,0 +1,250 @@
+// Polynomial glue of UnivariateKzgPCS::open on the device (reference
+// pcs/src/univariate_kzg/mod.rs:153-158,174): witness polynomial (f(X) - f(z)) / (X - z) by
+// synthetic division and f(z) by Horner, both as one suffix recurrence
+//     s_i = f_i + z * s_{i+1},  s_n = 0     =>  witness_{i-1} = s_i (i >= 1),  f(z) = s_0,
+// evaluated as a chunked scan (chunk-local Horner values, recursive carry computation with
+// multiplier z^K, then a second sweep), so the serial depth is O(K log_K n) instead of n.
+// Also: element-wise field ops for the test surface and the peak-rate probes for bench.py.
+#include "common.hpp"
+#include "curve.hpp"
+
+namespace jf {
+
+constexpr uint32_t HORNER_K = 64;
+
+// h[c] = sum_{k<K} in[cK + k] mu^k   (top chunk may be short)
+template <class Fr>
+__global__ __launch_bounds__(128) void k_horner_chunks(const uint32_t* __restrict__ in, uint32_t m,
+                                                       const uint32_t* __restrict__ mu_p, uint32_t* __restrict__ h) {
+    constexpr int N = Fr::N;
+    uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t lo = (uint64_t)c * HORNER_K;
+    if (lo >= m) return;
+    uint32_t hi = (uint32_t)((lo + HORNER_K < m) ? lo + HORNER_K : m);
+    Fp<Fr> mu = fp_load<Fr>(mu_p);
+    Fp<Fr> acc = Fp<Fr>::zero();
+    for (uint32_t k = hi; k-- > (uint32_t)lo;) acc = fp_add<Fr>(fp_mul<Fr>(acc, mu), fp_load<Fr>(in + (size_t)k * N));
+    fp_store<Fr>(h + (size_t)c * N, acc);
+}
+
+// s[k] = in[k] + mu * s[k+1] inside chunk c, seeded with the suffix value entering the chunk:
+// carry_src[c + 1] (the upper level's suffix array), or 0 for the top chunk / top level.
+template <class Fr>
+__global__ __launch_bounds__(128) void k_horner_apply(const uint32_t* __restrict__ in, uint32_t m,
+                                                      const uint32_t* __restrict__ mu_p,
+                                                      const uint32_t* __restrict__ carry_src, uint32_t n_carry,
+                                                      uint32_t* __restrict__ s) {
+    constexpr int N = Fr::N;
+    uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t lo = (uint64_t)c * HORNER_K;
+    if (lo >= m) return;
+    uint32_t hi = (uint32_t)((lo + HORNER_K < m) ? lo + HORNER_K : m);
+    Fp<Fr> mu = fp_load<Fr>(mu_p);
+    Fp<Fr> acc = Fp<Fr>::zero();
+    if (carry_src && c + 1 < n_carry) acc = fp_load<Fr>(carry_src + (size_t)(c + 1) * N);
+    for (uint32_t k = hi; k-- > (uint32_t)lo;) {
+        acc = fp_add<Fr>(fp_mul<Fr>(acc, mu), fp_load<Fr>(in + (size_t)k * N));
+        fp_store<Fr>(s + (size_t)k * N, acc);
+    }
+}
+
+// mus[l] = z^(K^l), l < levels
+template <class Fr>
+__global__ void k_horner_mus(const uint32_t* __restrict__ z, uint32_t levels, uint32_t* __restrict__ mus) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    Fp<Fr> mu = fp_load<Fr>(z);
+    for (uint32_t l = 0; l < levels; l++) {
+        fp_store<Fr>(mus + (size_t)l * Fr::N, mu);
+        mu = fp_pow_u64<Fr>(mu, HORNER_K);
+    }
+}
+
+template <class Fr>
+static int32_t open_witness_t(const uint32_t* d_coeffs, size_t n, const uint32_t* d_point, uint32_t* d_suffix,
+                              jfhip_stream* st) {
+    // d_suffix receives s_0 .. s_{n-1}; the witness is d_suffix + one element, eval is s_0
+    constexpr int N = Fr::N;
+    // level sizes
+    std::vector<size_t> sizes;
+    sizes.push_back(n);
+    while (sizes.back() > HORNER_K) sizes.push_back((sizes.back() + HORNER_K - 1) / HORNER_K);
+    const uint32_t levels = (uint32_t)sizes.size();
+    size_t extra = 0;
+    for (uint32_t l = 1; l < levels; l++) extra += sizes[l];
+    JF_TRY(st->poly_b.ensure((extra * 2 + levels + 1) * N * 4));
+    uint32_t* hbuf = st->poly_b.as<uint32_t>();          // chunk values of levels 1..
+    uint32_t* sbuf = hbuf + extra * N;                    // their suffix arrays
+    uint32_t* mus = sbuf + extra * N;
+    hipLaunchKernelGGL((k_horner_mus<Fr>), dim3(1), dim3(64), 0, st->s, d_point, levels, mus);
+    std::vector<uint32_t*> h(levels), s(levels);
+    h[0] = const_cast<uint32_t*>(d_coeffs);
+    s[0] = d_suffix;
+    size_t o = 0;
+    for (uint32_t l = 1; l < levels; l++) {
+        h[l] = hbuf + o * N;
+        s[l] = sbuf + o * N;
+        o += sizes[l];
+    }
+    for (uint32_t l = 1; l < levels; l++) {
+        unsigned blocks = (unsigned)((sizes[l] + 127) / 128);
+        hipLaunchKernelGGL((k_horner_chunks<Fr>), dim3(blocks), dim3(128), 0, st->s, h[l - 1], (uint32_t)sizes[l - 1],
+                           mus + (size_t)(l - 1) * N, h[l]);
+    }
+    for (uint32_t l = levels; l-- > 0;) {
+        size_t chunks = (sizes[l] + HORNER_K - 1) / HORNER_K;
+        unsigned blocks = (unsigned)((chunks + 127) / 128);
+        const uint32_t* carry = (l + 1 < levels) ? s[l + 1] : nullptr;
+        uint32_t n_carry = (l + 1 < levels) ? (uint32_t)sizes[l + 1] : 0u;
+        hipLaunchKernelGGL((k_horner_apply<Fr>), dim3(blocks), dim3(128), 0, st->s, h[l], (uint32_t)sizes[l],
+                           mus + (size_t)l * N, carry, n_carry, s[l]);
+    }
+    JF_HIP(hipGetLastError());
+    return JFHIP_OK;
+}
+
+int32_t open_witness_device(int32_t curve, const uint32_t* d_coeffs, size_t n, const uint32_t* d_point,
+                            uint32_t* d_witness, uint32_t* d_eval, jfhip_stream* st) {
+    // d_witness: n elements of scratch-and-result: [0] = eval, [1..n) = witness coefficients
+    (void)d_eval;
+    if (n == 0) return JFHIP_OK;
+    if (curve == JFHIP_BN254) return open_witness_t<Bn254Fr>(d_coeffs, n, d_point, d_witness, st);
+    return open_witness_t<Bls381Fr>(d_coeffs, n, d_point, d_witness, st);
+}
+
+// ---- element-wise field ops (test surface) ------------------------------------------------------
+template <class C>
+__global__ __launch_bounds__(128) void k_field_op(int op, const uint32_t* __restrict__ a,
+                                                  const uint32_t* __restrict__ b, uint32_t* __restrict__ out,
+                                                  uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fp<C> x = fp_load<C>(a + (size_t)i * C::N);
+    Fp<C> y = (op <= 2) ? fp_load<C>(b + (size_t)i * C::N) : Fp<C>::zero();
+    Fp<C> r;
+    switch (op) {
+    case 0: r = fp_add<C>(x, y); break;
+    case 1: r = fp_sub<C>(x, y); break;
+    case 2: r = fp_mul<C>(x, y); break;
+    case 3: r = fp_neg<C>(x); break;
+    case 4: r = fp_inv<C>(x); break;
+    case 5: r = fp_from_mont<C>(x); break;
+    default: r = fp_to_mont<C>(x); break;
+    }
+    fp_store<C>(out + (size_t)i * C::N, r);
+}
+
+int32_t field_op_device(int32_t field_id, int32_t op, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t n,
+                        hipStream_t s) {
+    dim3 grid((unsigned)((n + 127) / 128)), blk(128);
+    switch (field_id) {
+    case 0: hipLaunchKernelGGL((k_field_op<Bn254Fr>), grid, blk, 0, s, op, a, b, out, (uint32_t)n); break;
+    case 1: hipLaunchKernelGGL((k_field_op<Bn254Fq>), grid, blk, 0, s, op, a, b, out, (uint32_t)n); break;
+    case 2: hipLaunchKernelGGL((k_field_op<Bls381Fr>), grid, blk, 0, s, op, a, b, out, (uint32_t)n); break;
+    case 3: hipLaunchKernelGGL((k_field_op<Bls381Fq>), grid, blk, 0, s, op, a, b, out, (uint32_t)n); break;
+    default: set_error("unknown field id %d", field_id); return JFHIP_ERR_INVALID;
+    }
+    JF_HIP(hipGetLastError());
+    return JFHIP_OK;
+}
+
+// ---- peak-rate probes ---------------------------------------------------------------------------
+// 8 independent v_mad_u64_u32 chains per lane
+__global__ __launch_bounds__(256) void k_probe_mad(uint32_t iters, uint32_t seed, uint64_t* __restrict__ out) {
+    uint32_t a = seed + threadIdx.x * 2654435761u, b = (seed ^ blockIdx.x) | 1u;
+    uint64_t c0 = a, c1 = b, c2 = a ^ b, c3 = a + b, c4 = a * 3u, c5 = b * 5u, c6 = a * 7u, c7 = b * 9u;
+    for (uint32_t i = 0; i < iters; i++) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            c0 = (uint64_t)(uint32_t)c0 * b + c0;
+            c1 = (uint64_t)(uint32_t)c1 * a + c1;
+            c2 = (uint64_t)(uint32_t)c2 * b + c2;
+            c3 = (uint64_t)(uint32_t)c3 * a + c3;
+            c4 = (uint64_t)(uint32_t)c4 * b + c4;
+            c5 = (uint64_t)(uint32_t)c5 * a + c5;
+            c6 = (uint64_t)(uint32_t)c6 * b + c6;
+            c7 = (uint64_t)(uint32_t)c7 * a + c7;
+        }
+    }
+    uint64_t r = c0 ^ c1 ^ c2 ^ c3 ^ c4 ^ c5 ^ c6 ^ c7;
+    if (r == 0x1234567ull) out[0] = r;  // keep the chains live
+}
+
+__global__ __launch_bounds__(256) void k_probe_copy(const uint4* __restrict__ in, uint4* __restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) out[i] = in[i];
+}
+
+template <class C>
+__global__ __launch_bounds__(256) void k_probe_mul(uint32_t iters, uint32_t seed, uint32_t* __restrict__ out) {
+    Fp<C> x = Fp<C>::one(), y = Fp<C>::r2();
+    x.v[0] ^= (threadIdx.x & 1);
+    y.v[1] ^= seed & 1;
+    x = fp_reduce_once<C>(x);
+    for (uint32_t i = 0; i < iters; i++) {
+        x = fp_mul<C>(x, y);
+        y = fp_mul<C>(y, x);
+    }
+    if (x.v[0] == 0x12345u && y.v[1] == 0x777u) out[0] = x.v[2];
+}
+
+int32_t probe(int32_t kind, int32_t arg, double* out) {
+    hipEvent_t e0, e1;
+    JF_HIP(hipEventCreate(&e0));
+    JF_HIP(hipEventCreate(&e1));
+    float ms = 0;
+    double work = 0;
+    void* scratch = nullptr;
+    JF_HIP(hipMalloc(&scratch, 4096));
+    if (kind == 0) {
+        const uint32_t iters = 4096, blocks = 256 * 16;
+        hipLaunchKernelGGL(k_probe_mad, dim3(blocks), dim3(256), 0, 0, 64u, 1u, (uint64_t*)scratch);
+        JF_HIP(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL(k_probe_mad, dim3(blocks), dim3(256), 0, 0, iters, 1u, (uint64_t*)scratch);
+        JF_HIP(hipEventRecord(e1, 0));
+        work = (double)blocks * 256.0 * iters * 32.0;
+    } else if (kind == 1) {
+        const size_t bytes = (size_t)1 << 30;
+        void *a = nullptr, *b = nullptr;
+        JF_HIP(hipMalloc(&a, bytes));
+        JF_HIP(hipMalloc(&b, bytes));
+        JF_HIP(hipMemset(a, 1, bytes));
+        hipLaunchKernelGGL(k_probe_copy, dim3(256 * 16), dim3(256), 0, 0, (const uint4*)a, (uint4*)b, bytes / 16);
+        JF_HIP(hipEventRecord(e0, 0));
+        for (int r = 0; r < 4; r++)
+            hipLaunchKernelGGL(k_probe_copy, dim3(256 * 16), dim3(256), 0, 0, (const uint4*)a, (uint4*)b, bytes / 16);
+        JF_HIP(hipEventRecord(e1, 0));
+        JF_HIP(hipEventSynchronize(e1));
+        JF_HIP(hipFree(a));
+        JF_HIP(hipFree(b));
+        work = 4.0 * 2.0 * (double)bytes;
+    } else if (kind == 2) {
+        const uint32_t iters = 512, blocks = 256 * 8;
+        auto launch = [&](uint32_t it) {
+            switch (arg) {
+            case 0: hipLaunchKernelGGL((k_probe_mul<Bn254Fr>), dim3(blocks), dim3(256), 0, 0, it, 1u, (uint32_t*)scratch); break;
+            case 1: hipLaunchKernelGGL((k_probe_mul<Bn254Fq>), dim3(blocks), dim3(256), 0, 0, it, 1u, (uint32_t*)scratch); break;
+            case 2: hipLaunchKernelGGL((k_probe_mul<Bls381Fr>), dim3(blocks), dim3(256), 0, 0, it, 1u, (uint32_t*)scratch); break;
+            default: hipLaunchKernelGGL((k_probe_mul<Bls381Fq>), dim3(blocks), dim3(256), 0, 0, it, 1u, (uint32_t*)scratch); break;
+            }
+        };
+        launch(8);
+        JF_HIP(hipEventRecord(e0, 0));
+        launch(iters);
+        JF_HIP(hipEventRecord(e1, 0));
+        work = (double)blocks * 256.0 * iters * 2.0;
+    } else {
+        set_error("unknown probe kind %d", kind);
+        return JFHIP_ERR_INVALID;
+    }
+    JF_HIP(hipGetLastError());
+    JF_HIP(hipEventSynchronize(e1));
+    JF_HIP(hipEventElapsedTime(&ms, e0, e1));
+    JF_HIP(hipFree(scratch));
+    JF_HIP(hipEventDestroy(e0));
+    JF_HIP(hipEventDestroy(e1));
+    *out = work / ((double)ms * 1e-3);
+    return JFHIP_OK;
+}
+
+}  // namespace jf

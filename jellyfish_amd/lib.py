@@ -1,0 +1,302 @@
+"""ctypes binding of libjfhip.so -- one Python function per C-ABI entry point of include/jfhip.h.
+
+Arrays are numpy ``uint64`` (Montgomery little-endian limbs, exactly the bytes arkworks holds
+in ``Fp.0.0``); device pointers are plain integers (e.g. ``torch.Tensor.data_ptr()``).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import numpy as np
+
+BN254 = 0
+BLS12_381 = 1
+CURVE_IDS = {"bn254": BN254, "bls12_381": BLS12_381}
+FQ_LIMBS64 = {BN254: 4, BLS12_381: 6}
+
+_LIB = None
+
+
+class JfHipError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"jfhip error {code}: {msg}")
+        self.code = code
+        self.msg = msg
+
+
+def library_path() -> str:
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "libjfhip.so")
+
+
+# every symbol include/jfhip.h declares
+SYMBOLS = [
+    "jfhip_init", "jfhip_last_error", "jfhip_device_count", "jfhip_stream_create", "jfhip_stream_destroy",
+    "jfhip_stream_sync", "jfhip_stream_raw", "jfhip_stream_wrap", "jfhip_srs_load", "jfhip_srs_load_device",
+    "jfhip_srs_gen_for_testing", "jfhip_srs_free", "jfhip_srs_len", "jfhip_srs_window_bits", "jfhip_srs_read",
+    "jfhip_msm", "jfhip_msm_batch", "jfhip_msm_device", "jfhip_msm_partial_device", "jfhip_g1_sum_partials",
+    "jfhip_kzg_open", "jfhip_ntt", "jfhip_ntt_device", "jfhip_field_op", "jfhip_g1_op", "jfhip_probe",
+    "jfhip_set_profiling", "jfhip_last_phase_ms", "jfhip_phase_name",
+]
+
+
+def load_library():
+    """Load libjfhip.so; raises if it has not been built (no fallback path exists)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise FileNotFoundError(
+            f"{path} not found: build it with `make -C jellyfish_amd/csrc` (or __graft_entry__.build())")
+    lib = ctypes.CDLL(path)
+    for s in SYMBOLS:
+        getattr(lib, s).restype = ctypes.c_int32
+    lib.jfhip_srs_len.restype = ctypes.c_size_t
+    lib.jfhip_stream_raw.restype = ctypes.c_void_p
+    lib.jfhip_phase_name.restype = ctypes.c_char_p
+    _LIB = lib
+    return lib
+
+
+def last_error() -> str:
+    buf = ctypes.create_string_buffer(600)
+    load_library().jfhip_last_error(buf, ctypes.c_size_t(600))
+    return buf.value.decode(errors="replace")
+
+
+def _check(rc: int):
+    if rc != 0:
+        raise JfHipError(rc, last_error())
+
+
+def _u64(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.uint64)
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _vp(x):
+    return ctypes.c_void_p(int(x)) if x is not None else None
+
+
+def init(device: int = -1):
+    _check(load_library().jfhip_init(device))
+
+
+def device_count() -> int:
+    return load_library().jfhip_device_count()
+
+
+class Stream:
+    """jfhip_stream: a HIP stream plus its workspace (warmup_new_stream, pcs/src/lib.rs:430-435)."""
+
+    def __init__(self, wrap_raw: int | None = None):
+        h = ctypes.c_void_p()
+        if wrap_raw is None:
+            _check(load_library().jfhip_stream_create(ctypes.byref(h)))
+        else:
+            _check(load_library().jfhip_stream_wrap(_vp(wrap_raw), ctypes.byref(h)))
+        self.h = h
+
+    def sync(self):
+        _check(load_library().jfhip_stream_sync(self.h))
+
+    @property
+    def raw(self) -> int:
+        return int(load_library().jfhip_stream_raw(self.h) or 0)
+
+    def close(self):
+        if self.h:
+            load_library().jfhip_stream_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _sh(stream):
+    return stream.h if stream is not None else None
+
+
+class Srs:
+    """Device-resident prover parameters (powers_of_g), GPUCommittable::load_prover_param_to_gpu."""
+
+    def __init__(self, handle, curve: int):
+        self.h = handle
+        self.curve = curve
+
+    @classmethod
+    def load(cls, curve: int, points, window_bits: int = 0, stride_bytes: int | None = None) -> "Srs":
+        pts = np.ascontiguousarray(points)
+        pt_bytes = 16 * FQ_LIMBS64[curve]
+        if stride_bytes is None:
+            stride_bytes = pt_bytes
+        n = pts.nbytes // stride_bytes
+        h = ctypes.c_void_p()
+        _check(load_library().jfhip_srs_load(curve, _p(pts), ctypes.c_size_t(n), ctypes.c_size_t(stride_bytes),
+                                             window_bits, ctypes.byref(h)))
+        return cls(h, curve)
+
+    @classmethod
+    def load_device(cls, curve: int, d_points: int, n: int, window_bits: int = 0) -> "Srs":
+        h = ctypes.c_void_p()
+        _check(load_library().jfhip_srs_load_device(curve, _vp(d_points), ctypes.c_size_t(n), window_bits,
+                                                    ctypes.byref(h)))
+        return cls(h, curve)
+
+    @classmethod
+    def gen_for_testing(cls, curve: int, beta_mont, g_xy, n: int, window_bits: int = 0) -> "Srs":
+        beta, g = _u64(beta_mont), _u64(g_xy)
+        h = ctypes.c_void_p()
+        _check(load_library().jfhip_srs_gen_for_testing(curve, _p(beta), _p(g), ctypes.c_size_t(n), window_bits,
+                                                        ctypes.byref(h)))
+        return cls(h, curve)
+
+    def __len__(self) -> int:
+        return int(load_library().jfhip_srs_len(self.h))
+
+    @property
+    def window_bits(self) -> int:
+        return int(load_library().jfhip_srs_window_bits(self.h))
+
+    def read(self, offset: int, n: int) -> np.ndarray:
+        out = np.zeros((n, 2 * FQ_LIMBS64[self.curve]), dtype=np.uint64)
+        _check(load_library().jfhip_srs_read(self.h, ctypes.c_size_t(offset), ctypes.c_size_t(n), _p(out)))
+        return out
+
+    def free(self):
+        if self.h:
+            load_library().jfhip_srs_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def msm(srs: Srs, scalars_mont, offset: int = 0, stream: Stream | None = None):
+    """-> (packed affine point as uint64[2*fq_limbs], is_identity)"""
+    sc = _u64(scalars_mont)
+    n = sc.size // 4
+    out = np.zeros(2 * FQ_LIMBS64[srs.curve], dtype=np.uint64)
+    inf = ctypes.c_uint8(0)
+    _check(load_library().jfhip_msm(srs.h, ctypes.c_size_t(offset), _p(sc) if n else None, ctypes.c_size_t(n), _p(out),
+                                    ctypes.byref(inf), _sh(stream)))
+    return out, bool(inf.value)
+
+
+def msm_batch(srs: Srs, polys, stream: Stream | None = None):
+    arrs = [_u64(p) for p in polys]
+    batch = len(arrs)
+    ql = 2 * FQ_LIMBS64[srs.curve]
+    out = np.zeros((batch, ql), dtype=np.uint64)
+    inf = np.zeros(batch, dtype=np.uint8)
+    ptrs = (ctypes.c_void_p * max(batch, 1))(*[a.ctypes.data if a.size else None for a in arrs])
+    lens = (ctypes.c_size_t * max(batch, 1))(*[a.size // 4 for a in arrs])
+    _check(load_library().jfhip_msm_batch(srs.h, ptrs, lens, ctypes.c_size_t(batch), _p(out), _p(inf), _sh(stream)))
+    return out, inf.astype(bool)
+
+
+def msm_device(srs: Srs, d_scalars: int, n: int, d_out: int, offset: int = 0, stream: Stream | None = None):
+    _check(load_library().jfhip_msm_device(srs.h, ctypes.c_size_t(offset), _vp(d_scalars), ctypes.c_size_t(n),
+                                           _vp(d_out), _sh(stream)))
+
+
+def msm_partial_device(srs: Srs, d_scalars: int, n: int, d_out_xyzz: int, offset: int = 0,
+                       stream: Stream | None = None):
+    _check(load_library().jfhip_msm_partial_device(srs.h, ctypes.c_size_t(offset), _vp(d_scalars), ctypes.c_size_t(n),
+                                                   _vp(d_out_xyzz), _sh(stream)))
+
+
+def g1_sum_partials(curve: int, d_partials: int, count: int, d_out: int, stream: Stream | None = None):
+    _check(load_library().jfhip_g1_sum_partials(curve, _vp(d_partials), ctypes.c_size_t(count), _vp(d_out),
+                                                _sh(stream)))
+
+
+def kzg_open(srs: Srs, coeffs_mont, point_mont, stream: Stream | None = None):
+    """-> (proof packed affine, is_identity, eval limbs)"""
+    c, z = _u64(coeffs_mont), _u64(point_mont)
+    n = c.size // 4
+    out = np.zeros(2 * FQ_LIMBS64[srs.curve], dtype=np.uint64)
+    ev = np.zeros(4, dtype=np.uint64)
+    inf = ctypes.c_uint8(0)
+    _check(load_library().jfhip_kzg_open(srs.h, _p(c) if n else None, ctypes.c_size_t(n), _p(z), _p(out),
+                                         ctypes.byref(inf), _p(ev), _sh(stream)))
+    return out, bool(inf.value), ev
+
+
+def ntt(curve: int, data, log_n: int, inverse: bool = False, coset_mont=None, in_len: int = 0,
+        stream: Stream | None = None) -> np.ndarray:
+    """data: (batch, 2^log_n, 4) uint64 -> transformed copy (natural order in and out)."""
+    d = np.array(data, dtype=np.uint64, order="C", copy=True)
+    n = 1 << log_n
+    batch = d.size // (4 * n)
+    if batch * 4 * n != d.size:
+        raise ValueError("data size is not a multiple of the domain size")
+    cs = _u64(coset_mont) if coset_mont is not None else None
+    _check(load_library().jfhip_ntt(curve, _p(d), log_n, ctypes.c_size_t(batch), int(bool(inverse)),
+                                    _p(cs) if cs is not None else None, ctypes.c_size_t(in_len), _sh(stream)))
+    return d
+
+
+def ntt_device(curve: int, d_data: int, log_n: int, batch: int, inverse: bool = False, coset_mont=None,
+               in_len: int = 0, stream: Stream | None = None):
+    cs = _u64(coset_mont) if coset_mont is not None else None
+    _check(load_library().jfhip_ntt_device(curve, _vp(d_data), log_n, ctypes.c_size_t(batch), int(bool(inverse)),
+                                           _p(cs) if cs is not None else None, ctypes.c_size_t(in_len), _sh(stream)))
+
+
+FIELD_OPS = {"add": 0, "sub": 1, "mul": 2, "neg": 3, "inv": 4, "from_mont": 5, "to_mont": 6}
+
+
+def field_op(field_id: int, op: str, a, b=None) -> np.ndarray:
+    a = _u64(a)
+    nl = 6 if field_id == 3 else 4
+    n = a.size // nl
+    out = np.zeros_like(a)
+    bb = _u64(b) if b is not None else None
+    _check(load_library().jfhip_field_op(field_id, FIELD_OPS[op], _p(a), _p(bb) if bb is not None else None, _p(out),
+                                         ctypes.c_size_t(n)))
+    return out
+
+
+def g1_add(curve: int, P, Q) -> np.ndarray:
+    P, Q = _u64(P), _u64(Q)
+    out = np.zeros(2 * FQ_LIMBS64[curve], dtype=np.uint64)
+    _check(load_library().jfhip_g1_op(curve, 0, _p(P), _p(Q), _p(out)))
+    return out
+
+
+def g1_mul(curve: int, P, k_mont) -> np.ndarray:
+    P, k = _u64(P), _u64(k_mont)
+    out = np.zeros(2 * FQ_LIMBS64[curve], dtype=np.uint64)
+    _check(load_library().jfhip_g1_op(curve, 1, _p(P), _p(k), _p(out)))
+    return out
+
+
+def probe(kind: int, arg: int = 0) -> float:
+    r = ctypes.c_double(0)
+    _check(load_library().jfhip_probe(kind, arg, ctypes.byref(r)))
+    return r.value
+
+
+def set_profiling(enabled: bool):
+    load_library().jfhip_set_profiling(int(enabled))
+
+
+def last_phase_ms(stream: Stream | None = None, kind: int = 0) -> dict:
+    arr = (ctypes.c_double * 16)()
+    n = load_library().jfhip_last_phase_ms(_sh(stream), arr, 16)
+    out = {}
+    for i in range(n):
+        name = load_library().jfhip_phase_name(kind, i).decode()
+        out[name or f"phase{i}"] = arr[i]
+    return out

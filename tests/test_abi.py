@@ -1,0 +1,55 @@
+"""CPU suite: the C-ABI library loads and exports every symbol include/jfhip.h declares, and the
+host-side argument checks answer without a GPU (no compute calls here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from jellyfish_amd import lib as L
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "jfhip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(jfhip_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = L.load_library()
+    syms = declared_symbols()
+    assert len(syms) >= 25
+    for s in syms:
+        assert hasattr(lib, s), s
+    assert sorted(L.SYMBOLS) == syms
+
+
+def test_no_device_is_reported_not_crashed():
+    if L.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(L.JfHipError) as e:
+        L.init(0)
+    assert e.value.code == -3
+    assert "HIP device" in e.value.msg
+
+
+def test_argument_checks_without_gpu():
+    lib = L.load_library()
+    h = ctypes.c_void_p()
+    assert lib.jfhip_srs_load(7, None, ctypes.c_size_t(4), ctypes.c_size_t(64), 0, ctypes.byref(h)) == -1
+    assert lib.jfhip_msm(None, ctypes.c_size_t(0), None, ctypes.c_size_t(0), None, None, None) == -1
+    assert "SRS" in L.last_error()
+    assert lib.jfhip_msm_batch(None, None, None, ctypes.c_size_t(0), None, None, None) == -1
+    assert lib.jfhip_field_op(9, 0, None, None, None, ctypes.c_size_t(1)) == -1
+    assert lib.jfhip_phase_name(0, 2) == b"bucket_accumulate"
+
+
+def test_product_does_not_import_oracle():
+    """The oracle is test infrastructure: nothing under jellyfish_amd/ may reference it."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "jellyfish_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "oracle" not in text.replace("test oracle", ""), os.path.join(dirpath, f)

@@ -1,0 +1,61 @@
+"""GPU parity: field and group arithmetic of the HIP kernels vs the oracle, through the C ABI.
+Bar: bit-exact (integer arithmetic)."""
+import numpy as np
+import pytest
+
+from oracle import coracle as C
+from oracle import pyref as R
+from tests.util import FIELD_ID, golden, gpt, h2i, mont_arr, pt_arr, pt_from
+
+pytestmark = pytest.mark.gpu
+CURVES = [R.BN254, R.BLS12_381]
+FIELDS = {x.name: x for cv in CURVES for x in (cv.fr, cv.fq)}
+
+
+@pytest.mark.parametrize("fname", list(FIELD_ID))
+def test_field_ops_golden_and_random(hip, fname):
+    f = FIELDS[fname]
+    fid = FIELD_ID[fname]
+    g = golden("field")[fname]
+    a = mont_arr(f, [h2i(x) for x in g["a"]])
+    b = mont_arr(f, [h2i(x) for x in g["b"]])
+    for op in ("add", "sub", "mul"):
+        assert (hip.field_op(fid, op, a, b) == mont_arr(f, [h2i(x) for x in g[op]])).all(), op
+    for op in ("neg", "inv"):
+        assert (hip.field_op(fid, op, a) == mont_arr(f, [h2i(x) for x in g[op]])).all(), op
+    # random bulk vs the C oracle
+    rng = R.SplitMix64(99 + fid)
+    n = 4096
+    xs = [rng.field(f) for _ in range(n)]
+    ys = [rng.field(f) for _ in range(n)]
+    A, B = mont_arr(f, xs), mont_arr(f, ys)
+    for op in ("add", "sub", "mul"):
+        assert (hip.field_op(fid, op, A, B) == C.fp_binop(fid, op, A, B)).all(), op
+    assert (hip.field_op(fid, "neg", A) == C.fp_unop(fid, "neg", A)).all()
+    assert (hip.field_op(fid, "inv", A[:256]) == C.fp_unop(fid, "inv", A[:256])).all()
+    assert (hip.field_op(fid, "from_mont", A) == C.fp_unop(fid, "from_mont", A)).all()
+    assert (hip.field_op(fid, "to_mont", A) == C.fp_unop(fid, "to_mont", A)).all()
+    # outputs fully reduced
+    out = hip.field_op(fid, "mul", A, B)
+    vals = [R.Field.from_limbs(row) for row in out]
+    assert max(vals) < f.p
+
+
+@pytest.mark.parametrize("cv", CURVES, ids=lambda c: c.name)
+def test_group_ops(hip, cv):
+    k = golden("constants")[cv.name]
+    G = pt_arr(cv, cv.g)
+    assert pt_from(cv, hip.g1_add(cv.curve_id, G, G)) == gpt(k["g2"])
+    neg = pt_arr(cv, R.ec_neg(cv, cv.g))
+    assert pt_from(cv, hip.g1_add(cv.curve_id, G, neg)) is None
+    zero = np.zeros_like(G)
+    assert (hip.g1_add(cv.curve_id, G, zero) == G).all()
+    assert (hip.g1_add(cv.curve_id, zero, G) == G).all()
+    rng = R.SplitMix64(5)
+    for _ in range(3):
+        s = rng.field(cv.fr)
+        sm = mont_arr(cv.fr, [s])[0]
+        assert (hip.g1_mul(cv.curve_id, G, sm) == C.ec_mul(cv.curve_id, G, sm)).all()
+    # order * G = identity
+    rm1 = mont_arr(cv.fr, [cv.fr.p - 1])[0]
+    assert pt_from(cv, hip.g1_mul(cv.curve_id, G, rm1)) == R.ec_neg(cv, cv.g)

@@ -1,0 +1,168 @@
+"""GPU parity for the MSM path (UnivariateKzgPCS::commit / batch_commit, SRS loading) through the
+C ABI, following the protocol of the reference's test_gpu_e2e
+(pcs/src/univariate_kzg/mod.rs:1359-1414): GPU commitment == CPU commitment, as affine points,
+bit for bit."""
+import numpy as np
+import pytest
+
+from oracle import coracle as C
+from oracle import pyref as R
+from tests.util import golden, gpt, h2i, mont_arr, pt_arr, pt_from, rand_fr_mont, seeded_scalars
+
+pytestmark = pytest.mark.gpu
+CURVES = [R.BN254, R.BLS12_381]
+
+
+@pytest.fixture(scope="module", params=CURVES, ids=lambda c: c.name)
+def setup(request, hip):
+    cv = request.param
+    g = golden("msm")[cv.name]
+    beta, gen = h2i(g["beta"]), gpt(g["g"])
+    n = (1 << 12) + 8
+    srs_host = C.srs_gen(cv.curve_id, mont_arr(cv.fr, [beta])[0], pt_arr(cv, gen), n)
+    srs = hip.Srs.load(cv.curve_id, srs_host)
+    yield cv, g, srs_host, srs
+    srs.free()
+
+
+def test_srs_gen_matches_oracle_and_golden(hip, setup):
+    cv, g, srs_host, _ = setup
+    beta, gen = h2i(g["beta"]), gpt(g["g"])
+    dev = hip.Srs.gen_for_testing(cv.curve_id, mont_arr(cv.fr, [beta])[0], pt_arr(cv, gen), len(srs_host))
+    got = dev.read(0, len(srs_host))
+    assert (got == srs_host).all()
+    for i, p in g["srs_spot"].items():
+        assert pt_from(cv, got[int(i)]) == gpt(p)
+    dev.free()
+
+
+def test_msm_golden_cases(hip, setup):
+    cv, g, srs_host, srs = setup
+    for case in g["cases"]:
+        n, off = case["n"], case["offset"]
+        sc = [h2i(s) for s in case["scalars"]] if "scalars" in case else seeded_scalars(cv, case["scalar_seed"], n)
+        out, inf = hip.msm(srs, mont_arr(cv.fr, sc), offset=off)
+        exp = gpt(case["expect"])
+        assert pt_from(cv, out) == exp, (n, case["set"])
+        assert inf == (exp is None)
+
+
+@pytest.mark.parametrize("c", [4, 7, 13])
+def test_msm_window_sizes_and_arbitrary_bases(hip, setup, c):
+    """exceptional additions (P+P, P-P, identity bases) at several window sizes"""
+    cv, g, _, _ = setup
+    bases = np.array([pt_arr(cv, gpt(p)) for p in g["arbitrary_bases"]])
+    srs = hip.Srs.load(cv.curve_id, bases, window_bits=c)
+    assert srs.window_bits == c
+    for case in g["arbitrary_cases"]:
+        sc = mont_arr(cv.fr, [h2i(s) for s in case["scalars"]])
+        out, inf = hip.msm(srs, sc)
+        assert pt_from(cv, out) == gpt(case["expect"]), (c, case["set"])
+    srs.free()
+
+
+def test_srs_load_strided_with_infinity_flag(hip, setup):
+    """arkworks' in-memory G1Affine {x, y, infinity: bool} records (stride 72 / 104 bytes)"""
+    cv, g, srs_host, _ = setup
+    n = 50
+    pt_bytes = 16 * cv.fq.limbs64
+    stride = pt_bytes + 8
+    raw = np.zeros((n, stride), dtype=np.uint8)
+    raw[:, :pt_bytes] = srs_host[:n].view(np.uint8).reshape(n, pt_bytes)
+    raw[7, pt_bytes] = 1  # flagged identity with stale coordinates
+    srs = hip.Srs.load(cv.curve_id, raw, stride_bytes=stride)
+    sc = rand_fr_mont(cv, n, 3)
+    bases = srs_host[:n].copy()
+    bases[7] = 0
+    out, _ = hip.msm(srs, sc)
+    assert (out == C.msm(cv.curve_id, bases, sc)).all()
+    srs.free()
+
+
+def test_gpu_e2e_protocol(hip, setup):
+    """10 rounds of random degree < 1025 (reference :1371-1387), then batches of 10..14 (:1389-1401),
+    the empty batch (:1402-1405) and a ragged batch."""
+    cv, _, srs_host, srs = setup
+    rng = np.random.default_rng(17)
+    for rnd in range(10):
+        deg = int(rng.integers(1, 1025))
+        sc = rand_fr_mont(cv, deg + 1, 100 + rnd)
+        out, inf = hip.msm(srs, sc)
+        assert (out == C.msm(cv.curve_id, srs_host[:deg + 1], sc)).all()
+        assert not inf
+    for bs in range(10, 15):
+        polys = [rand_fr_mont(cv, 1025, 1000 + 20 * bs + i) for i in range(bs)]
+        outs, infs = hip.msm_batch(srs, polys)
+        for i, p in enumerate(polys):
+            assert (outs[i] == C.msm(cv.curve_id, srs_host[:1025], p)).all()
+    outs, infs = hip.msm_batch(srs, [])
+    assert outs.shape[0] == 0
+    polys = [rand_fr_mont(cv, n, 4000 + n) for n in (1, 17, 1000)] + [np.zeros((0, 4), dtype=np.uint64)]
+    outs, infs = hip.msm_batch(srs, polys)
+    for i, p in enumerate(polys[:3]):
+        assert (outs[i] == C.msm(cv.curve_id, srs_host[:len(p)], p)).all()
+    assert infs[3] and not outs[3].any()
+
+
+def test_degenerate_inputs(hip, setup):
+    cv, _, srs_host, srs = setup
+    # zero polynomial and empty polynomial -> identity
+    out, inf = hip.msm(srs, np.zeros((64, 4), dtype=np.uint64))
+    assert inf and not out.any()
+    out, inf = hip.msm(srs, np.zeros((0, 4), dtype=np.uint64))
+    assert inf and not out.any()
+    # all coefficients equal (one bucket per window receives everything)
+    n = 3000
+    one = mont_arr(cv.fr, [1])[0]
+    for val in (one, mont_arr(cv.fr, [cv.fr.p - 1])[0], mont_arr(cv.fr, [0xFFFFFFFFFFFF])[0]):
+        sc = np.tile(val, (n, 1))
+        out, inf = hip.msm(srs, sc)
+        assert (out == C.msm(cv.curve_id, srs_host[:n], sc)).all()
+    # sparse 0/1 witness-like vector
+    sc = np.zeros((n, 4), dtype=np.uint64)
+    idx = np.random.default_rng(3).integers(0, n, size=n // 3)
+    sc[idx] = one
+    out, _ = hip.msm(srs, sc)
+    assert (out == C.msm(cv.curve_id, srs_host[:n], sc)).all()
+    # degree check: "poly degree {} is larger than allowed {}" (mod.rs:100-106)
+    with pytest.raises(hip.JfHipError) as e:
+        hip.msm(srs, rand_fr_mont(cv, len(srs_host) + 1, 1))
+    assert e.value.code == -1 and "larger than allowed" in e.value.msg
+
+
+@pytest.mark.parametrize("log_n", [16, 18])
+def test_msm_vs_oracle_large(hip, log_n):
+    """BN254 at 2^16 / 2^18: full comparison with the C oracle; SRS generated on the device."""
+    cv = R.BN254
+    n = (1 << log_n) + 1
+    beta = mont_arr(cv.fr, [0xBEEF0000 + log_n])[0]
+    srs = hip.Srs.gen_for_testing(cv.curve_id, beta, pt_arr(cv, cv.g), n)
+    srs_host = srs.read(0, n)
+    # spot-check the device SRS against [beta^i] g from the oracle
+    for i in (0, 1, n // 2, n - 1):
+        bi = C.fp_unop(0, "to_mont", np.array(cv.fr.limbs(pow(0xBEEF0000 + log_n, i, cv.fr.p)), dtype=np.uint64))
+        assert (srs_host[i] == C.ec_mul(cv.curve_id, pt_arr(cv, cv.g), bi)).all()
+    sc = rand_fr_mont(cv, n, 11)
+    out, inf = hip.msm(srs, sc)
+    assert (out == C.msm(cv.curve_id, srs_host, sc)).all()
+    srs.free()
+
+
+def test_msm_full_size_closed_form(hip):
+    """BASELINE config 2 size (2^20 BN254): commit == [p(beta)] g, a size-independent identity,
+    plus linearity commit(a) + commit(b) == commit(a + b)."""
+    cv = R.BN254
+    n = 1 << 20
+    beta = mont_arr(cv.fr, [0x6A660001])[0]
+    G = pt_arr(cv, cv.g)
+    srs = hip.Srs.gen_for_testing(cv.curve_id, beta, G, n)
+    a = rand_fr_mont(cv, n, 21)
+    b = rand_fr_mont(cv, n, 22)
+    ca, _ = hip.msm(srs, a)
+    cb, _ = hip.msm(srs, b)
+    pa = C.poly_eval(cv.curve_id, a, beta)
+    assert (ca == C.ec_mul(cv.curve_id, G, pa)).all()
+    s = C.fp_binop(0, "add", a, b)
+    cs, _ = hip.msm(srs, s)
+    assert (cs == C.ec_add(cv.curve_id, ca, cb)).all()
+    srs.free()

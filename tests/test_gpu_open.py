@@ -1,0 +1,47 @@
+"""GPU parity for UnivariateKzgPCS::open (pcs/src/univariate_kzg/mod.rs:144-180) through the C ABI:
+witness polynomial by synthetic division + its commitment + the evaluation."""
+import numpy as np
+import pytest
+
+from oracle import coracle as C
+from oracle import pyref as R
+from tests.util import from_mont_arr, golden, gpt, h2i, mont_arr, pt_arr, pt_from, rand_fr_mont
+
+pytestmark = pytest.mark.gpu
+CURVES = [R.BN254, R.BLS12_381]
+
+
+@pytest.mark.parametrize("cv", CURVES, ids=lambda c: c.name)
+def test_open_golden(hip, cv):
+    g = golden("open")[cv.name]
+    beta = mont_arr(cv.fr, [h2i(g["beta"])])[0]
+    srs = hip.Srs.gen_for_testing(cv.curve_id, beta, pt_arr(cv, gpt(g["g"])), 512)
+    for case in g["cases"]:
+        coeffs = mont_arr(cv.fr, [h2i(c) for c in case["coeffs"]])
+        z = mont_arr(cv.fr, [h2i(case["z"])])[0]
+        proof, inf, ev = hip.kzg_open(srs, coeffs, z)
+        assert from_mont_arr(cv.fr, ev)[0] == h2i(case["eval"]), case["n"]
+        assert pt_from(cv, proof) == gpt(case["proof"]), case["n"]
+        assert inf == (case["proof"] is None)
+        out, _ = hip.msm(srs, coeffs)
+        assert pt_from(cv, out) == gpt(case["commitment"])
+    # empty polynomial
+    proof, inf, ev = hip.kzg_open(srs, np.zeros((0, 4), dtype=np.uint64), beta)
+    assert inf and not ev.any()
+    srs.free()
+
+
+@pytest.mark.parametrize("n", [63, 64, 65, 4096, 4097, 100000])
+def test_open_vs_oracle(hip, n):
+    """chunk boundaries of the scan (K = 64) and a multi-level size"""
+    cv = R.BN254
+    beta = mont_arr(cv.fr, [424242])[0]
+    srs = hip.Srs.gen_for_testing(cv.curve_id, beta, pt_arr(cv, cv.g), n)
+    srs_host = srs.read(0, n)
+    coeffs = rand_fr_mont(cv, n, 900 + n)
+    z = rand_fr_mont(cv, 1, 5)[0]
+    proof, inf, ev = hip.kzg_open(srs, coeffs, z)
+    q, e = C.open_witness(cv.curve_id, coeffs, z)
+    assert (ev == e).all()
+    assert (proof == C.msm(cv.curve_id, srs_host[:n - 1], q)).all()
+    srs.free()

@@ -1,0 +1,85 @@
+"""Shared helpers for the tests: conversions between Python integers and the boundary's
+Montgomery limb arrays, deterministic inputs, golden fixture access."""
+from __future__ import annotations
+
+import json
+import os
+
+import numpy as np
+
+from oracle import pyref as R
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+FIELD_ID = {"bn254_fr": 0, "bn254_fq": 1, "bls12_381_fr": 2, "bls12_381_fq": 3}
+
+
+def golden(name: str):
+    with open(os.path.join(GOLDEN, name + ".json")) as f:
+        return json.load(f)
+
+
+def h2i(s) -> int:
+    return int(s, 16)
+
+
+def mont_arr(f: R.Field, xs) -> np.ndarray:
+    """integers -> (len, limbs64) uint64 Montgomery limbs"""
+    return np.array([f.mont_limbs(x) for x in xs], dtype=np.uint64).reshape(len(xs), f.limbs64)
+
+
+def from_mont_arr(f: R.Field, a) -> list[int]:
+    a = np.asarray(a, dtype=np.uint64).reshape(-1, f.limbs64)
+    return [f.from_mont(R.Field.from_limbs(row)) for row in a]
+
+
+def pt_arr(cv: R.Curve, P) -> np.ndarray:
+    n = cv.fq.limbs64
+    if P is None:
+        return np.zeros(2 * n, dtype=np.uint64)
+    return np.array(cv.fq.mont_limbs(P[0]) + cv.fq.mont_limbs(P[1]), dtype=np.uint64)
+
+
+def pt_from(cv: R.Curve, a):
+    n = cv.fq.limbs64
+    a = np.asarray(a, dtype=np.uint64).reshape(-1)
+    x = R.Field.from_limbs(a[:n])
+    y = R.Field.from_limbs(a[n:2 * n])
+    if x == 0 and y == 0:
+        return None
+    return (cv.fq.from_mont(x), cv.fq.from_mont(y))
+
+
+def gpt(p):
+    """golden point ([hexx, hexy] or None) -> tuple"""
+    return None if p is None else (h2i(p[0]), h2i(p[1]))
+
+
+def seeded_scalars(cv: R.Curve, seed: int, n: int) -> list[int]:
+    rng = R.SplitMix64(seed)
+    return [rng.field(cv.fr) for _ in range(n)]
+
+
+def rand_fr_mont(cv: R.Curve, n: int, seed: int) -> np.ndarray:
+    """n uniformly random Fr elements as Montgomery limbs (any canonical value < r is a valid
+    Montgomery representative, so uniform limbs below r are uniform field elements)."""
+    rng = np.random.default_rng(seed)
+    bits = cv.fr.p.bit_length()
+    out = rng.integers(0, 1 << 64, size=(n, 4), dtype=np.uint64)
+    out[:, 3] &= np.uint64((1 << (bits - 192)) - 1)
+    p_limbs = np.array(cv.fr.limbs(cv.fr.p), dtype=np.uint64)
+    while True:
+        # lexicographic compare (top limb first) against p
+        ge = np.zeros(n, dtype=bool)
+        decided = np.zeros(n, dtype=bool)
+        for l in (3, 2, 1, 0):
+            gt = (out[:, l] > p_limbs[l]) & ~decided
+            lt = (out[:, l] < p_limbs[l]) & ~decided
+            ge |= gt
+            decided |= gt | lt
+        ge |= ~decided
+        bad = np.nonzero(ge)[0]
+        if bad.size == 0:
+            return out
+        fresh = rng.integers(0, 1 << 64, size=(bad.size, 4), dtype=np.uint64)
+        fresh[:, 3] &= np.uint64((1 << (bits - 192)) - 1)
+        out[bad] = fresh
