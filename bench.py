@@ -1,0 +1,256 @@
+#!/usr/bin/env python3
+"""bench.py -- jellyfish PLONK proving hot path on MI355X: MSM throughput (Mpts/s).
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line.
+A "step" is one BN254 G1 MSM (the arithmetic of UnivariateKzgPCS::commit, reference
+pcs/src/univariate_kzg/mod.rs:90-125) over 2^24 points per GPU with the SRS and the scalars
+already resident in HBM.  At N > 1 the point range is partitioned over the ranks
+(N * 2^24 points in total, weak scaling) and the only exchange is an RCCL all_gather of one
+group element per GPU.
+
+Extra objects on the same line:
+  roofline      dominant kernel (bucket accumulation), INT32 VALU multiply-add rate vs the
+                v_mad_u64_u32 peak measured live on the same device (SURVEY.md 8d names INT32
+                VALU, not HBM or MFMA, as the bound of this kernel); hbm_view gives the same
+                launch against the 8 TB/s HBM peak.
+  cpu_baseline  the CPU restatement (oracle/, kind "port") timed on the host cores on a bounded
+                sample of the same workload.  The reference's own rayon/arkworks prover cannot be
+                built here (no Rust toolchain), see DESIGN.md.
+  ntt           BASELINE config 3 (8 x 2^22 BLS12-381 Fr coset NTT, forward + inverse) measured
+                in the same run with its HBM roofline.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+LOG_N = 24
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+# BN254 G1 generator (1, 2), Montgomery limbs
+BN254_G = np.array([0xd35d438dc58f0d9d, 0x0a78eb28f5c70b3d, 0x666ea36f7879462c, 0x0e0a77c19a07df2f,
+                    0xa6ba871b8b1e1b3a, 0x14f1d651eb8e167b, 0xccdd46def0f28c58, 0x1c14ef83340fbe5e], dtype=np.uint64)
+BN254_R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+BLS_R = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+
+
+def uniform_fr(n: int, seed: int, modulus: int) -> np.ndarray:
+    """n uniform field elements (rejection sampling), as 4 x u64 limbs.  Any value < r is a valid
+    Montgomery representative, so these are uniform scalars in the boundary's format."""
+    rng = np.random.default_rng(seed)
+    bits = modulus.bit_length()
+    top_mask = np.uint64((1 << (bits - 192)) - 1)
+    p = np.array([(modulus >> (64 * i)) & (2**64 - 1) for i in range(4)], dtype=np.uint64)
+    out = rng.integers(0, 1 << 64, size=(n, 4), dtype=np.uint64)
+    out[:, 3] &= top_mask
+    while True:
+        ge = np.zeros(n, dtype=bool)
+        decided = np.zeros(n, dtype=bool)
+        for l in (3, 2, 1, 0):
+            gt = (out[:, l] > p[l]) & ~decided
+            lt = (out[:, l] < p[l]) & ~decided
+            ge |= gt
+            decided |= gt | lt
+        ge |= ~decided
+        bad = np.nonzero(ge)[0]
+        if bad.size == 0:
+            return out
+        fresh = rng.integers(0, 1 << 64, size=(bad.size, 4), dtype=np.uint64)
+        fresh[:, 3] &= top_mask
+        out[bad] = fresh
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--log-n", type=int, default=LOG_N, help="points per GPU = 2^log_n (metric: 24)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ntt", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from jellyfish_amd import dist as jdist
+    from jellyfish_amd import lib as L
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    L.load_library()
+    L.init(local_rank if world > 1 else 0)
+
+    n = 1 << args.log_n
+    # SRS shard of this rank: [beta^(rank*n + i)] g, i < n   (gen_srs_for_testing shape)
+    beta = uniform_fr(1, 0x6A660001, BN254_R)[0]
+    g = BN254_G
+    if rank:
+        # g' = [beta^(rank*n)] g: fold the exponent with the device scalar multiplication
+        shift = beta
+        e = rank * n
+        acc = None
+        base = beta.copy()
+        while e:
+            if e & 1:
+                acc = base.copy() if acc is None else L.field_op(0, "mul", acc, base)
+            base = L.field_op(0, "mul", base, base)
+            e >>= 1
+        g = L.g1_mul(0, g, acc)
+    t0 = time.time()
+    srs = L.Srs.gen_for_testing(0, beta, g, n)
+    srs_build_s = time.time() - t0
+    scalars_host = uniform_fr(n, 0xC0FFEE + rank, BN254_R)
+    scalars = torch.from_numpy(scalars_host.view(np.int64)).cuda()
+    stream = L.Stream(wrap_raw=torch.cuda.current_stream().cuda_stream)
+    engine = jdist.HipMsmEngine(L, srs, stream)
+
+    def step():
+        return jdist.sharded_msm(engine, scalars)
+
+    for _ in range(args.warmup):
+        res = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    result_bytes = bytes(res.cpu().numpy().tobytes())
+
+    out = None
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * n * args.steps / elapsed / 1e6
+        out = {
+            "metric": "MSM throughput, BN254 G1, 2^%d points per GPU (UnivariateKzgPCS::commit arithmetic)" % args.log_n,
+            "value": round(value, 3), "unit": "Mpts/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32 limbs (256-bit Montgomery, INT32 VALU)", "data": "synthetic",
+            "config": {"workload": "msm_bn254_g1_2^%d_per_gpu" % args.log_n, "curve": "bn254",
+                       "points_per_gpu": n, "total_points": world * n, "window_bits": srs.window_bits,
+                       "srs": "[beta^i]g generated on device (%.2f s incl. window-multiple table)" % srs_build_s,
+                       "scalars": "uniform in [0,r), Montgomery form, resident in HBM",
+                       "sharding": "point ranges per rank + all_gather of one XYZZ element per GPU" if world > 1 else "single GPU"},
+            "result_sha": __import__("hashlib").sha256(result_bytes).hexdigest()[:16],
+        }
+
+    # ---- roofline of the dominant kernel + secondary measurements: rank 0, N = 1 only ----------
+    if rank == 0 and world == 1:
+        L.set_profiling(True)
+        reps = max(3, min(args.steps, 10))
+        acc_ms, phases_sum = 0.0, {}
+        for _ in range(reps):
+            L.msm_device(srs, scalars.data_ptr(), n, engine._out.data_ptr(), stream=stream)
+            ph = L.last_phase_ms(stream, 0)
+            for k, v in ph.items():
+                phases_sum[k] = phases_sum.get(k, 0.0) + v
+        L.set_profiling(False)
+        phases = {k: round(v / reps, 4) for k, v in phases_sum.items()}
+        acc_ms = phases.get("bucket_accumulate", float("nan"))
+        c = srs.window_bits
+        windows = (255 + c - 1) // c
+        macs_per_point = windows * 10 * 136  # W windows x (8M+2S mixed add) x (2*8^2+8) MACs per Montgomery product
+        macs = float(macs_per_point) * n
+        mad_peak = L.probe(0)
+        copy_bw = L.probe(1)
+        achieved = macs / (acc_ms * 1e-3)
+        alg_bytes = 96.0 * n  # 64 B affine point + 32 B scalar per point
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if os.path.exists(pmc_path):
+            try:
+                pmc = json.load(open(pmc_path))
+                if pmc.get("workload") == out["config"]["workload"]:
+                    traffic = pmc.get("k_msm_accumulate_hbm_bytes")
+            except Exception:
+                traffic = None
+        out["roofline"] = {
+            "kernel": "k_msm_accumulate", "bound": "valu_int32",
+            "achieved": round(achieved / 1e12, 4), "peak": round(mad_peak / 1e12, 4), "unit": "TMAC/s (v_mad_u64_u32)",
+            "frac": round(achieved / mad_peak, 4), "traffic": traffic,
+            "algorithmic": "%d windows x 10 field mul x 136 MAC = %d MAC/point x 2^%d points" % (windows, macs_per_point, args.log_n),
+            "avg_launch_ms": acc_ms,
+            "peak_source": "v_mad_u64_u32 issue-rate micro-benchmark on this device (jfhip_probe 0); not in MI355X_MICROARCH.md",
+            "hbm_view": {"bound": "hbm", "achieved": round(alg_bytes / (acc_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(alg_bytes / (acc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                         "measured_copy_GBs": round(copy_bw / 1e9, 1)},
+        }
+        out["phases_ms"] = phases
+
+        if not args.no_ntt:
+            log_m, batch = 22, 8
+            m = 1 << log_m
+            d = torch.from_numpy(uniform_fr(batch * m, 5, BLS_R).view(np.int64)).cuda()
+            h = L.field_op(2, "to_mont", np.array([7, 0, 0, 0], dtype=np.uint64))
+            L.set_profiling(True)
+            res_ntt = {}
+            for inverse in (False, True):
+                L.ntt_device(1, d.data_ptr(), log_m, batch, inverse, h, stream=stream)
+                stream.sync()
+                ts = []
+                for _ in range(5):
+                    L.ntt_device(1, d.data_ptr(), log_m, batch, inverse, h, stream=stream)
+                    ts.append(sum(L.last_phase_ms(stream, 1).values()))
+                ms = float(np.median(ts))
+                gbs = batch * m * 64 / (ms * 1e-3) / 1e9
+                res_ntt["inverse" if inverse else "forward"] = {
+                    "ms": round(ms, 4), "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+                                                     "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}}
+            L.set_profiling(False)
+            out["ntt"] = {"workload": "8 x 2^22 BLS12-381 Fr coset NTT (h = 7), device resident",
+                          "algorithmic_bytes": "64 B per element per transform", **res_ntt}
+
+        if not args.no_cpu_baseline:
+            try:
+                from oracle import coracle as C
+
+                log_s = min(args.log_n, 21)
+                ns = 1 << log_s
+                bases = srs.read(0, ns)
+                threads = C.nthreads()
+                t0 = time.perf_counter()
+                cpu_res = C.msm(0, bases, scalars_host[:ns], threads)
+                dt = time.perf_counter() - t0
+                gpu_res, _ = L.msm(srs, scalars_host[:ns])
+                out["cpu_baseline"] = {
+                    "value": round(ns / dt / 1e6, 4), "unit": "Mpts/s", "cores": threads, "kind": "port",
+                    "sample": "one MSM over the first 2^%d points/scalars of the same SRS and scalar set (%.1f s)" % (log_s, dt),
+                    "matches_gpu": bool((cpu_res == gpu_res).all()),
+                    "note": "CPU restatement (oracle/jf_oracle.c, OpenMP Pippenger), not arkworks: no Rust toolchain on the box"}
+            except Exception as e:  # the baseline is reporting only; never fail the bench on it
+                out["cpu_baseline"] = {"value": None, "unit": "Mpts/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    srs.free()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -62,7 +62,7 @@ JF_HD XYZZ<Cv> xyzz_from_affine(const Affine<Cv>& p) {
 
 // 2 * (affine p), p != identity   (EFD mdbl-2008-s-1, a = 0)
 template <class Cv>
-JF_HD XYZZ<Cv> xyzz_double_affine(const Affine<Cv>& p) {
+JF_COLD XYZZ<Cv> xyzz_double_affine(const Affine<Cv>& p) {
     using Q = typename Cv::Fq;
     XYZZ<Cv> r;
     auto U = fp_dbl<Q>(p.y);
@@ -80,7 +80,7 @@ JF_HD XYZZ<Cv> xyzz_double_affine(const Affine<Cv>& p) {
 
 // 2 * p   (EFD dbl-2008-s-1, a = 0); identity and y = 0 map to identity
 template <class Cv>
-JF_HD XYZZ<Cv> xyzz_double(const XYZZ<Cv>& p) {
+JF_COLD XYZZ<Cv> xyzz_double(const XYZZ<Cv>& p) {
     using Q = typename Cv::Fq;
     if (p.is_inf() || p.Y.is_zero()) return XYZZ<Cv>::identity();
     XYZZ<Cv> r;
@@ -128,7 +128,7 @@ JF_HD void xyzz_add_affine(XYZZ<Cv>& acc, const Affine<Cv>& q) {
 
 // acc += q   (EFD add-2008-s)
 template <class Cv>
-JF_HD void xyzz_add(XYZZ<Cv>& acc, const XYZZ<Cv>& q) {
+JF_COLD void xyzz_add(XYZZ<Cv>& acc, const XYZZ<Cv>& q) {
     using Q = typename Cv::Fq;
     if (q.is_inf()) return;
     if (acc.is_inf()) {
@@ -159,7 +159,7 @@ JF_HD void xyzz_add(XYZZ<Cv>& acc, const XYZZ<Cv>& q) {
 
 // exact affine normalisation: one field inversion
 template <class Cv>
-JF_HD Affine<Cv> xyzz_to_affine(const XYZZ<Cv>& p) {
+JF_COLD Affine<Cv> xyzz_to_affine(const XYZZ<Cv>& p) {
     using Q = typename Cv::Fq;
     Affine<Cv> r;
     if (p.is_inf()) {

@@ -15,6 +15,7 @@ namespace jf {
 
 #define JF_DEV __device__ __forceinline__
 #define JF_HD __host__ __device__ __forceinline__
+#define JF_COLD __device__ __noinline__
 
 // ---- field parameter packs -------------------------------------------------------------
 struct Bn254Fr {
@@ -299,14 +300,28 @@ JF_HD Fp<C> fp_to_mont(const Fp<C>& a) {
     return fp_mul<C>(a, Fp<C>::r2());
 }
 
-// a^(p-2) (Fermat); inv(0) = 0.  Exponent bits come from the constexpr modulus.
+// limb i of p - 2, with borrow propagation (BLS12-381 Fr has low limb 1)
 template <class C>
-JF_HD Fp<C> fp_inv(const Fp<C>& a) {
+JF_HD constexpr uint32_t pm2_limb(int i) {
+    uint32_t borrow = 2, r = 0;
+    for (int k = 0; k <= i; k++) {
+        uint64_t d = (uint64_t)C::P(k) - borrow;
+        r = (uint32_t)d;
+        borrow = (uint32_t)(d >> 32) & 1u;
+    }
+    return r;
+}
+
+// a^(p-2) (Fermat); inv(0) = 0.  Exponent bits come from the constexpr modulus.
+// Out of line: it is large and only ever on cold, latency-bound paths.
+template <class C>
+__device__ __noinline__ Fp<C> fp_inv(const Fp<C>& a) {
     constexpr int N = C::N;
     Fp<C> acc = Fp<C>::one();
-    // p - 2 : only limb 0 changes for every modulus here (low limb >= 2)
     for (int i = N - 1; i >= 0; i--) {
-        uint32_t e = C::P(i) - (i == 0 ? 2u : 0u);
+        uint32_t e = 0;
+#pragma unroll
+        for (int j = 0; j < N; j++) e = (j == i) ? pm2_limb<C>(j) : e;
         for (int b = 31; b >= 0; b--) {
             acc = fp_sqr<C>(acc);
             if ((e >> b) & 1u) acc = fp_mul<C>(acc, a);

@@ -84,5 +84,9 @@ def test_ntt_config3_shape_properties(hip):
 
 
 def test_ntt_rejects_oversize(hip):
-    with pytest.raises(hip.JfHipError):
-        hip.ntt(0, np.zeros((1, 2, 4), dtype=np.uint64), 29)
+    """log_n beyond the field's two-adicity (28 for BN254 Fr) is refused before any launch"""
+    import ctypes
+
+    lib = hip.load_library()
+    rc = lib.jfhip_ntt_device(0, ctypes.c_void_p(256), 29, ctypes.c_size_t(1), 0, None, ctypes.c_size_t(0), None)
+    assert rc == -1 and "two-adicity" in hip.last_error()
