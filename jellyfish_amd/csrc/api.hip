@@ -89,7 +89,7 @@ jfhip_stream* resolve_stream(jfhip_stream* s) {
 }
 
 static void stream_release(jfhip_stream* s) {
-    DevBuf* bufs[] = {&s->scalars, &s->dig,  &s->sorted, &s->counts, &s->offs,   &s->cursor, &s->bsum,
+    DevBuf* bufs[] = {&s->scalars, &s->dig, &s->dig2, &s->midbase, &s->midcnt, &s->midcur, &s->finecnt, &s->finecur, &s->sorted, &s->counts, &s->offs,   &s->cursor, &s->bsum,
                       &s->buckets, &s->partA, &s->partB, &s->red0,   &s->red1,   &s->result, &s->ntt_tmp,
                       &s->ntt_io,  &s->poly_a, &s->poly_b, &s->poly_c};
     for (DevBuf* b : bufs) b->release();
@@ -615,7 +615,7 @@ int32_t jfhip_last_phase_ms(jfhip_stream* stream, double* phases, int32_t cap) {
 }
 
 const char* jfhip_phase_name(int32_t kind, int32_t idx) {
-    static const char* msm[] = {"digits+histogram", "scan+scatter", "bucket_accumulate", "slice_fixup",
+    static const char* msm[] = {"coarse_histogram", "bucket_sort", "bucket_accumulate", "slice_fixup",
                                 "bucket_fold",      "sum_tree"};
     if (kind == 0) return (idx >= 0 && idx < 6) ? msm[idx] : "";
     static const char* ntt[] = {"pass0", "pass1", "pass2", "pass3"};

@@ -50,7 +50,7 @@ struct jfhip_stream {
     bool owned = false;
     std::mutex mu;  // one MSM/NTT at a time per stream object (workspace is per stream)
     // MSM workspace
-    jf::DevBuf scalars, dig, sorted, counts, offs, cursor, bsum, buckets, partA, partB, red0, red1, result;
+    jf::DevBuf scalars, dig, dig2, sorted, counts, offs, cursor, bsum, midbase, midcnt, midcur, finecnt, finecur, buckets, partA, partB, red0, red1, result;
     // NTT workspace
     jf::DevBuf ntt_tmp, ntt_io;
     // open()

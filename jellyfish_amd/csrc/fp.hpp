@@ -226,9 +226,10 @@ JF_HD Fp<C> fp_dbl(const Fp<C>& a) {
     return fp_reduce_once<C>(t);
 }
 
-// CIOS Montgomery product, operand-scanning, one 64-bit accumulator chain per row.
+// Portable CIOS Montgomery product (operand scanning).  Host code and the reference point for
+// the device version below.
 template <class C>
-JF_HD Fp<C> fp_mul(const Fp<C>& a, const Fp<C>& b) {
+JF_HD Fp<C> fp_mul_cios(const Fp<C>& a, const Fp<C>& b) {
     constexpr int N = C::N;
     uint32_t t[N + 1];
 #pragma unroll
@@ -262,6 +263,66 @@ JF_HD Fp<C> fp_mul(const Fp<C>& a, const Fp<C>& b) {
     for (int i = 0; i < N; i++) r.v[i] = t[i];
     return fp_reduce_once<C>(r);
 }
+
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(JF_FP_MUL_PORTABLE)
+// 96-bit column accumulator (lo64, hi32) += a * b : v_mad_u64_u32 accumulates in place and hands
+// its carry-out straight to v_addc_co_u32 through VCC -- one multiply-add and one add per limb
+// product, no register moves (the C++ form costs a 64-bit add plus two v_mov per product).
+JF_DEV void jf_mac(uint64_t& lo, uint32_t& hi, uint32_t a, uint32_t b) {
+    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
+        : "+v"(lo), "+v"(hi)
+        : "v"(a), "v"(b)
+        : "vcc");
+}
+// same with a wave-uniform (modulus) limb held in an SGPR
+JF_DEV void jf_mac_s(uint64_t& lo, uint32_t& hi, uint32_t a, uint32_t b_uniform) {
+    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
+        : "+v"(lo), "+v"(hi)
+        : "v"(a), "s"(b_uniform)
+        : "vcc");
+}
+
+// Montgomery product, finely integrated product scanning (FIPS): column i of a*b + m*p is summed
+// in one 96-bit accumulator, m[i] is chosen to clear its low word, the accumulator shifts down.
+template <class C>
+JF_DEV Fp<C> fp_mul(const Fp<C>& a, const Fp<C>& b) {
+    constexpr int N = C::N;
+    uint32_t m[N];
+    Fp<C> r;
+    uint64_t lo = 0;
+    uint32_t hi = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+#pragma unroll
+        for (int j = 0; j < i; j++) {
+            jf_mac(lo, hi, a.v[j], b.v[i - j]);
+            jf_mac_s(lo, hi, m[j], C::P(i - j));
+        }
+        jf_mac(lo, hi, a.v[i], b.v[0]);
+        m[i] = (uint32_t)lo * C::INV;
+        jf_mac_s(lo, hi, m[i], C::P(0));
+        lo = (lo >> 32) | ((uint64_t)hi << 32);
+        hi = 0;
+    }
+#pragma unroll
+    for (int i = N; i < 2 * N; i++) {
+#pragma unroll
+        for (int j = i - N + 1; j < N; j++) {
+            jf_mac(lo, hi, a.v[j], b.v[i - j]);
+            jf_mac_s(lo, hi, m[j], C::P(i - j));
+        }
+        r.v[i - N] = (uint32_t)lo;
+        lo = (lo >> 32) | ((uint64_t)hi << 32);
+        hi = 0;
+    }
+    return fp_reduce_once<C>(r);
+}
+#else
+template <class C>
+JF_HD Fp<C> fp_mul(const Fp<C>& a, const Fp<C>& b) {
+    return fp_mul_cios<C>(a, b);
+}
+#endif
 
 template <class C>
 JF_HD Fp<C> fp_sqr(const Fp<C>& a) {

@@ -38,34 +38,201 @@ JF_DEV uint32_t extract_bits(const uint32_t (&v)[N], int bit, int c) {
     return (uint32_t)(t >> sh) & ((1u << c) - 1u);
 }
 
-// scalar (Montgomery) -> W signed digits in [-2^(c-1), 2^(c-1)]; histogram of |digit|-1
-template <class Cv>
-__global__ __launch_bounds__(256) void k_msm_digits(const uint32_t* __restrict__ scalars, uint32_t n, int c, int W,
-                                                    int32_t* __restrict__ dig, uint32_t* __restrict__ count) {
-    using Fr = typename Cv::Fr;
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    Fp<Fr> s = fp_from_mont<Fr>(fp_load<Fr>(scalars + (size_t)i * Fr::N));
-    uint32_t carry = 0;
+// ---- two-level bucket sort of (bucket, table index) pairs -------------------------------------
+//
+// bucket id = |digit| - 1 in [0, 2^(c-1)) is split into coarse (top) and fine (low) bits.
+//   level 1: scalars -> signed digits (Montgomery reduction fused) -> entries appended to their
+//            COARSE bin.  A workgroup handles a tile of scalars with an LDS histogram, reserves
+//            its span of every coarse bin with ONE global atomic per bin, then scatters.
+//   level 2: one workgroup per coarse bin counting-sorts its entries by the fine bits with LDS
+//            atomics and emits the per-bucket offsets; its writes stay inside one L2-sized span.
+// No per-entry global atomics, no digit array; entries cost 8 B between the levels.
+
+constexpr int SORT_TILE_SCALARS = 2048;  // per workgroup of 256 lanes
+constexpr int MAX_COARSE_BITS = 10;
+constexpr int MAX_FINE_BITS = 18;  // consumed in one or two LDS levels of <= 9 bits
+
+struct DigitPlan {
+    int c, W, coarse_bits, fine_bits;
+};
+
+// signed digit of window w; carry in/out
+template <int N>
+JF_DEV int32_t signed_digit(const uint32_t (&v)[N], int w, int c, uint32_t& carry) {
+    int bit = w * c;
+    uint32_t raw = (bit < 32 * N) ? extract_bits<N>(v, bit, c) : 0u;
+    raw += carry;
     const uint32_t half = 1u << (c - 1);
-    for (int w = 0; w < W; w++) {
-        int bit = w * c;
-        uint32_t raw = (bit < 32 * Fr::N) ? extract_bits<Fr::N>(s.v, bit, c) : 0u;
-        raw += carry;
-        int32_t d;
-        if (raw > half) {
-            d = (int32_t)raw - (int32_t)(1u << c);
-            carry = 1;
-        } else {
-            d = (int32_t)raw;
-            carry = 0;
+    if (raw > half) {
+        carry = 1;
+        return (int32_t)raw - (int32_t)(1u << c);
+    }
+    carry = 0;
+    return (int32_t)raw;
+}
+
+// PASS = 0: coarse histogram only.  PASS = 1: reserve + scatter entries.
+template <class Cv, int PASS>
+__global__ __launch_bounds__(256) void k_msm_coarse(const uint32_t* __restrict__ scalars, uint32_t n, DigitPlan pl,
+                                                    uint32_t table_n, uint32_t offset,
+                                                    uint32_t* __restrict__ gcount /*PASS0: counts, PASS1: cursors*/,
+                                                    uint2* __restrict__ entries) {
+    using Fr = typename Cv::Fr;
+    __shared__ uint32_t hist[1 << MAX_COARSE_BITS];
+    __shared__ uint32_t base[1 << MAX_COARSE_BITS];
+    const uint32_t nb = 1u << pl.coarse_bits;
+    for (uint32_t k = threadIdx.x; k < nb; k += 256) hist[k] = 0;
+    __syncthreads();
+    const uint32_t tile0 = blockIdx.x * SORT_TILE_SCALARS;
+
+    for (int rep = 0; rep < SORT_TILE_SCALARS / 256; rep++) {
+        uint32_t i = tile0 + rep * 256 + threadIdx.x;
+        if (i < n) {
+            Fp<Fr> s = fp_from_mont<Fr>(fp_load<Fr>(scalars + (size_t)i * Fr::N));
+            uint32_t carry = 0;
+            for (int w = 0; w < pl.W; w++) {
+                int32_t d = signed_digit<Fr::N>(s.v, w, pl.c, carry);
+                if (d != 0) {
+                    uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1u;
+                    atomicAdd(&hist[b >> pl.fine_bits], 1u);
+                }
+            }
         }
-        dig[(size_t)w * n + i] = d;
-        if (d != 0) atomicAdd(&count[(d < 0 ? -d : d) - 1], 1u);
+    }
+    __syncthreads();
+    if (PASS == 0) {
+        for (uint32_t k = threadIdx.x; k < nb; k += 256)
+            if (hist[k]) atomicAdd(&gcount[k], hist[k]);
+        return;
+    }
+    for (uint32_t k = threadIdx.x; k < nb; k += 256) {
+        uint32_t h = hist[k];
+        base[k] = h ? atomicAdd(&gcount[k], h) : 0u;
+        hist[k] = 0;
+    }
+    __syncthreads();
+    for (int rep = 0; rep < SORT_TILE_SCALARS / 256; rep++) {
+        uint32_t i = tile0 + rep * 256 + threadIdx.x;
+        if (i < n) {
+            Fp<Fr> s = fp_from_mont<Fr>(fp_load<Fr>(scalars + (size_t)i * Fr::N));
+            uint32_t carry = 0;
+            for (int w = 0; w < pl.W; w++) {
+                int32_t d = signed_digit<Fr::N>(s.v, w, pl.c, carry);
+                if (d != 0) {
+                    uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1u;
+                    uint32_t cb = b >> pl.fine_bits;
+                    uint32_t pos = base[cb] + atomicAdd(&hist[cb], 1u);
+                    uint32_t payload = ((uint32_t)w * table_n + offset + i) | (d < 0 ? 0x80000000u : 0u);
+                    entries[pos] = make_uint2(payload, b);
+                }
+            }
+        }
     }
 }
 
-// ---- exclusive scan of the bucket histogram (3 small launches) ----------------------------
+// exclusive scan of the coarse counts (<= 1024) -> cbase[0..nb], cursors = cbase; off[B] = total
+__global__ __launch_bounds__(1024) void k_msm_coarse_scan(const uint32_t* __restrict__ ccount, uint32_t nb,
+                                                          uint32_t* __restrict__ cbase, uint32_t* __restrict__ cursor,
+                                                          uint32_t* __restrict__ off_total) {
+    __shared__ uint32_t sh[1024];
+    uint32_t v = threadIdx.x < nb ? ccount[threadIdx.x] : 0u;
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        uint32_t t = (threadIdx.x >= (unsigned)d) ? sh[threadIdx.x - d] : 0u;
+        __syncthreads();
+        sh[threadIdx.x] += t;
+        __syncthreads();
+    }
+    uint32_t excl = sh[threadIdx.x] - v;
+    if (threadIdx.x < nb) {
+        cbase[threadIdx.x] = excl;
+        cursor[threadIdx.x] = excl;
+    }
+    if (threadIdx.x == 1023) {
+        cbase[nb] = sh[1023];
+        *off_total = sh[1023];
+    }
+}
+
+// ---- refinement levels: equal-sized chunks of the entry array, any segment skew ----------------
+//
+// Input entries are grouped by the key bits above `shift + bits` (segments given by segbase).
+// A workgroup takes a fixed chunk of LVL_CHUNK consecutive entries -- so the load is balanced
+// whatever the bucket distribution (the top window alone puts 1/W of all entries into a handful
+// of coarse bins) -- walks the segments the chunk overlaps in groups that fit the LDS histogram,
+// and either counts (MODE 0) or reserves one span per (chunk, key) with a global atomic and
+// scatters (MODE 1: entries, MODE 2: final payloads).  Keys of one level are at most 9 bits so a
+// workgroup keeps few, L2-resident store frontiers.
+constexpr int LVL_CHUNK = 8192;
+constexpr int LVL_THREADS = 256;
+constexpr int LVL_LDS_KEYS = 4096;
+
+template <int MODE>
+__global__ __launch_bounds__(LVL_THREADS) void k_msm_level(const uint2* __restrict__ in,
+                                                           const uint32_t* __restrict__ segbase, uint32_t nseg,
+                                                           int shift, int bits, uint32_t* __restrict__ gcount,
+                                                           uint2* __restrict__ out_entries,
+                                                           uint32_t* __restrict__ out_sorted) {
+    __shared__ uint32_t cnt[LVL_LDS_KEYS];
+    __shared__ uint32_t base[LVL_LDS_KEYS];
+    const uint32_t total = segbase[nseg];
+    const uint64_t c0_64 = (uint64_t)blockIdx.x * LVL_CHUNK;
+    if (c0_64 >= total) return;
+    const uint32_t c0 = (uint32_t)c0_64;
+    const uint32_t c1 = (uint32_t)((c0_64 + LVL_CHUNK < total) ? c0_64 + LVL_CHUNK : total);
+    const uint32_t seg_per_group = LVL_LDS_KEYS >> bits;
+    // first segment overlapping the chunk: largest s with segbase[s] <= c0
+    uint32_t lo = 0, hi = nseg;
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (segbase[mid] <= c0) lo = mid;
+        else hi = mid;
+    }
+    uint32_t s0 = lo;
+    while (s0 < nseg) {
+        uint32_t s1 = (s0 + seg_per_group < nseg) ? s0 + seg_per_group : nseg;
+        uint32_t e_lo = segbase[s0], e_hi = segbase[s1];
+        if (e_lo >= c1) break;
+        if (e_lo < c0) e_lo = c0;
+        if (e_hi > c1) e_hi = c1;
+        if (e_hi > e_lo) {
+            const uint32_t nkeys = (s1 - s0) << bits;
+            for (uint32_t k = threadIdx.x; k < nkeys; k += LVL_THREADS) cnt[k] = 0;
+            __syncthreads();
+            // the bits above this level's key ARE the segment id, so the group-relative key is
+            // one subtraction
+            const uint32_t key0 = s0 << bits;
+            for (uint32_t e = e_lo + threadIdx.x; e < e_hi; e += LVL_THREADS)
+                atomicAdd(&cnt[(in[e].y >> shift) - key0], 1u);
+            __syncthreads();
+            uint32_t* g = gcount + ((size_t)s0 << bits);
+            if (MODE == 0) {
+                for (uint32_t k = threadIdx.x; k < nkeys; k += LVL_THREADS)
+                    if (cnt[k]) atomicAdd(&g[k], cnt[k]);
+            } else {
+                for (uint32_t k = threadIdx.x; k < nkeys; k += LVL_THREADS) {
+                    uint32_t h = cnt[k];
+                    base[k] = h ? atomicAdd(&g[k], h) : 0u;
+                    cnt[k] = 0;
+                }
+                __syncthreads();
+                for (uint32_t e = e_lo + threadIdx.x; e < e_hi; e += LVL_THREADS) {
+                    uint2 en = in[e];
+                    uint32_t key = (en.y >> shift) - key0;
+                    uint32_t pos = base[key] + atomicAdd(&cnt[key], 1u);
+                    if (MODE == 2) out_sorted[pos] = en.x;
+                    else out_entries[pos] = en;
+                }
+            }
+            __syncthreads();
+        }
+        if (segbase[s1] >= c1) break;
+        s0 = s1;
+    }
+}
+
+// ---- exclusive scan of up to 2^24 counters (3 small launches) ---------------------------------
 constexpr int SCAN_ITEMS = 8;
 constexpr int SCAN_BLOCK = 256;
 
@@ -131,21 +298,6 @@ __global__ __launch_bounds__(256) void k_scan_add(uint32_t* __restrict__ off, ui
     uint32_t v = off[i] + bsum[i / (SCAN_BLOCK * SCAN_ITEMS)];
     off[i] = v;
     cursor[i] = v;
-}
-
-// bucket-sort scatter: entry = table index | sign << 31
-__global__ __launch_bounds__(256) void k_msm_scatter(const int32_t* __restrict__ dig, uint32_t n, int W,
-                                                     uint32_t table_n, uint32_t offset,
-                                                     uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted) {
-    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    size_t total = (size_t)n * W;
-    if (idx >= total) return;
-    int32_t d = dig[idx];
-    if (d == 0) return;
-    uint32_t w = (uint32_t)(idx / n), i = (uint32_t)(idx % n);
-    uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1u;
-    uint32_t pos = atomicAdd(&cursor[b], 1u);
-    sorted[pos] = (w * table_n + offset + i) | (d < 0 ? 0x80000000u : 0u);
 }
 
 // One lane per slice of L consecutive sorted entries.  A run (maximal stretch of one bucket
@@ -622,14 +774,25 @@ static int32_t msm_partial_t(const jfhip_srs* srs, size_t offset, const uint32_t
     if (L < 16) L = 16;
     if (L > 256) L = 256;
     const size_t T = (total_max + L - 1) / L;
-    const uint32_t nblk = (B + SCAN_BLOCK * SCAN_ITEMS - 1) / (SCAN_BLOCK * SCAN_ITEMS);
+    DigitPlan pl;
+    pl.c = c;
+    pl.W = W;
+    pl.coarse_bits = (c - 1) - 8;
+    if (pl.coarse_bits < 0) pl.coarse_bits = 0;
+    if (pl.coarse_bits > MAX_COARSE_BITS) pl.coarse_bits = MAX_COARSE_BITS;
+    pl.fine_bits = (c - 1) - pl.coarse_bits;
+    if (pl.fine_bits > MAX_FINE_BITS) {
+        set_error("window_bits %d unsupported by the bucket sort (max %d)", c, MAX_COARSE_BITS + MAX_FINE_BITS + 1);
+        return JFHIP_ERR_INVALID;
+    }
+    const uint32_t nb = 1u << pl.coarse_bits;
 
-    JF_TRY(st->dig.ensure(total_max * 4));
+    JF_TRY(st->dig.ensure(total_max * 8));     // level-1 entries (payload, fine bucket)
     JF_TRY(st->sorted.ensure(total_max * 4));
-    JF_TRY(st->counts.ensure((size_t)B * 4));
+    JF_TRY(st->counts.ensure(((size_t)nb + 1) * 4));
     JF_TRY(st->offs.ensure(((size_t)B + 1) * 4));
-    JF_TRY(st->cursor.ensure((size_t)B * 4));
-    JF_TRY(st->bsum.ensure((size_t)nblk * 4));
+    JF_TRY(st->cursor.ensure(((size_t)nb + 1) * 4));
+    JF_TRY(st->bsum.ensure(((size_t)nb + 1) * 4));
     JF_TRY(st->buckets.ensure((size_t)B * XZ * 4));
     // fold: g buckets per lane, then a sum tree (the fold output reuses partA after the fix-up)
     uint32_t g = 16;
@@ -641,20 +804,66 @@ static int32_t msm_partial_t(const jfhip_srs* srs, size_t offset, const uint32_t
     uint32_t* counts = st->counts.as<uint32_t>();
     uint32_t* offs = st->offs.as<uint32_t>();
     uint32_t* cursor = st->cursor.as<uint32_t>();
-    uint32_t* bsum = st->bsum.as<uint32_t>();
+    uint32_t* cbase = st->bsum.as<uint32_t>();
     uint32_t* buckets = st->buckets.as<uint32_t>();
+    uint2* entries = st->dig.as<uint2>();
 
-    JF_HIP(hipMemsetAsync(counts, 0, (size_t)B * 4, st->s));
+    JF_HIP(hipMemsetAsync(counts, 0, ((size_t)nb + 1) * 4, st->s));
     JF_HIP(hipMemsetAsync(buckets, 0, (size_t)B * XZ * 4, st->s));
-    hipLaunchKernelGGL((k_msm_digits<Cv>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st->s, d_scalars,
-                       (uint32_t)n, c, W, st->dig.as<int32_t>(), counts);
+    const unsigned tiles = (unsigned)((n + SORT_TILE_SCALARS - 1) / SORT_TILE_SCALARS);
+    hipLaunchKernelGGL((k_msm_coarse<Cv, 0>), dim3(tiles), dim3(256), 0, st->s, d_scalars, (uint32_t)n, pl,
+                       (uint32_t)srs->n, (uint32_t)offset, counts, entries);
+    hipLaunchKernelGGL(k_msm_coarse_scan, dim3(1), dim3(1024), 0, st->s, counts, nb, cbase, cursor, offs + B);
     pt.mark();
-    hipLaunchKernelGGL(k_scan_local, dim3(nblk), dim3(SCAN_BLOCK), 0, st->s, counts, B, offs, bsum);
-    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(SCAN_BLOCK), 0, st->s, bsum, nblk, offs + B);
-    hipLaunchKernelGGL(k_scan_add, dim3((B + 255) / 256), dim3(256), 0, st->s, offs, B, bsum, cursor);
-    hipLaunchKernelGGL(k_msm_scatter, dim3((unsigned)((total_max + 255) / 256)), dim3(256), 0, st->s,
-                       st->dig.as<int32_t>(), (uint32_t)n, W, (uint32_t)srs->n, (uint32_t)offset, cursor,
-                       st->sorted.as<uint32_t>());
+    hipLaunchKernelGGL((k_msm_coarse<Cv, 1>), dim3(tiles), dim3(256), 0, st->s, d_scalars, (uint32_t)n, pl,
+                       (uint32_t)srs->n, (uint32_t)offset, cursor, entries);
+    {
+        // refinement levels over the fine bits: one level if <= 8 bits, else two
+        const unsigned chunks = (unsigned)((total_max + LVL_CHUNK - 1) / LVL_CHUNK);
+        auto scan = [&](uint32_t* cnts, uint32_t m, uint32_t* out_base, uint32_t* out_cursor) -> int32_t {
+            // out_base[0..m] = exclusive scan (out_base[m] = total), out_cursor = copy of out_base[0..m)
+            const uint32_t nblk = (m + SCAN_BLOCK * SCAN_ITEMS - 1) / (SCAN_BLOCK * SCAN_ITEMS);
+            JF_TRY(st->red0.ensure((size_t)nblk * 4));
+            uint32_t* bs = st->red0.as<uint32_t>();
+            hipLaunchKernelGGL(k_scan_local, dim3(nblk), dim3(SCAN_BLOCK), 0, st->s, cnts, m, out_base, bs);
+            hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(SCAN_BLOCK), 0, st->s, bs, nblk, out_base + m);
+            hipLaunchKernelGGL(k_scan_add, dim3((m + 255) / 256), dim3(256), 0, st->s, out_base, m, bs, out_cursor);
+            return JFHIP_OK;
+        };
+        const uint2* cur_entries = entries;
+        const uint32_t* cur_base = cbase;
+        uint32_t cur_nseg = nb;
+        int rem = pl.fine_bits;
+        if (rem > 8) {
+            const int lo_bits = rem / 2, hi_bits = rem - lo_bits;
+            const uint32_t nmid = nb << hi_bits;
+            JF_TRY(st->midbase.ensure(((size_t)nmid + 1) * 4));
+            JF_TRY(st->midcnt.ensure(((size_t)nmid + 1) * 4));
+            JF_TRY(st->midcur.ensure(((size_t)nmid + 1) * 4));
+            JF_TRY(st->dig2.ensure(total_max * 8));
+            JF_HIP(hipMemsetAsync(st->midcnt.p, 0, ((size_t)nmid + 1) * 4, st->s));
+            hipLaunchKernelGGL((k_msm_level<0>), dim3(chunks), dim3(LVL_THREADS), 0, st->s, cur_entries, cur_base,
+                               cur_nseg, lo_bits, hi_bits, st->midcnt.as<uint32_t>(), (uint2*)nullptr,
+                               (uint32_t*)nullptr);
+            JF_TRY(scan(st->midcnt.as<uint32_t>(), nmid, st->midbase.as<uint32_t>(), st->midcur.as<uint32_t>()));
+            hipLaunchKernelGGL((k_msm_level<1>), dim3(chunks), dim3(LVL_THREADS), 0, st->s, cur_entries, cur_base,
+                               cur_nseg, lo_bits, hi_bits, st->midcur.as<uint32_t>(), st->dig2.as<uint2>(),
+                               (uint32_t*)nullptr);
+            cur_entries = st->dig2.as<uint2>();
+            cur_base = st->midbase.as<uint32_t>();
+            cur_nseg = nmid;
+            rem = lo_bits;
+        }
+        JF_TRY(st->finecnt.ensure(((size_t)B + 1) * 4));
+        JF_TRY(st->finecur.ensure(((size_t)B + 1) * 4));
+        JF_HIP(hipMemsetAsync(st->finecnt.p, 0, ((size_t)B + 1) * 4, st->s));
+        hipLaunchKernelGGL((k_msm_level<0>), dim3(chunks), dim3(LVL_THREADS), 0, st->s, cur_entries, cur_base,
+                           cur_nseg, 0, rem, st->finecnt.as<uint32_t>(), (uint2*)nullptr, (uint32_t*)nullptr);
+        JF_TRY(scan(st->finecnt.as<uint32_t>(), B, offs, st->finecur.as<uint32_t>()));
+        hipLaunchKernelGGL((k_msm_level<2>), dim3(chunks), dim3(LVL_THREADS), 0, st->s, cur_entries, cur_base,
+                           cur_nseg, 0, rem, st->finecur.as<uint32_t>(), (uint2*)nullptr,
+                           st->sorted.as<uint32_t>());
+    }
     pt.mark();
     hipLaunchKernelGGL((k_msm_accumulate<Cv>), dim3((unsigned)((T + 127) / 128)), dim3(128), 0, st->s,
                        st->sorted.as<uint32_t>(), offs, B, srs->table, (uint32_t)L, buckets,
