@@ -1,0 +1,420 @@
+// Host-side mirror of the reference's operator interface for the accelerated path, written in C++
+// over the C ABI of jfhip.h (the reference's own host language, Rust, has no toolchain in the build
+// image; INTEGRATION.md shows the Rust FFI shim a maintainer adds instead of this header).
+//
+// Names, argument meaning and error behaviour follow the reference:
+//   PolynomialCommitmentScheme for UnivariateKzgPCS<E>     pcs/src/univariate_kzg/mod.rs:59-211
+//     commit / batch_commit / open / batch_open            :90-125 / :128-140 / :144-180 / :187-211
+//   GPUCommittable<E>                                      pcs/src/univariate_kzg/mod.rs:659-965
+//     gpu_commit, gpu_commit_with_loaded_prover_param, gpu_batch_commit,
+//     gpu_batch_commit_with_loaded_prover_param, load_prover_param_to_gpu, load_poly_to_gpu,
+//     load_batch_poly_to_gpu, commit_on_gpu, load_commitments_to_host
+//   warmup_new_stream                                      pcs/src/lib.rs:430-435
+//   PCSError::{InvalidParameters, UpstreamError}           pcs/src/errors.rs:19-34
+//   Radix2EvaluationDomain::{fft, ifft, fft_in_place, ifft_in_place, get_coset}  (ark-poly 0.5),
+//     as called at plonk/src/proof_system/prover.rs:524-573,658-660 and
+//     relation/src/constraint_system.rs:1369-1622
+//
+// Field elements are arkworks' in-memory representation: Montgomery little-endian u64 limbs.
+// Header-only; link with -ljfhip.  No arithmetic happens on the host.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "jfhip.h"
+
+namespace jf_pcs {
+
+// ---- curves ---------------------------------------------------------------------------------
+struct Bn254 {
+    static constexpr int32_t ID = JFHIP_BN254;
+    static constexpr int FQ_LIMBS = 4;
+    static constexpr uint32_t TWO_ADICITY = 28;
+    static constexpr uint64_t GENERATOR = 5;  // Fr::GENERATOR, the prover's coset offset
+};
+struct Bls12_381 {
+    static constexpr int32_t ID = JFHIP_BLS12_381;
+    static constexpr int FQ_LIMBS = 6;
+    static constexpr uint32_t TWO_ADICITY = 32;
+    static constexpr uint64_t GENERATOR = 7;
+};
+
+using Fr = std::array<uint64_t, 4>;  // E::ScalarField, Montgomery limbs (`Fp.0.0`)
+
+// ark_ec::short_weierstrass::Affine { x, y, infinity } with the same field order
+template <class E>
+struct G1Affine {
+    std::array<uint64_t, E::FQ_LIMBS> x{}, y{};
+    bool infinity = true;
+    static G1Affine zero() { return G1Affine{}; }
+    bool operator==(const G1Affine& o) const {
+        if (infinity || o.infinity) return infinity == o.infinity;
+        return x == o.x && y == o.y;
+    }
+};
+
+template <class E>
+struct Commitment {  // pcs/src/structs.rs:12-18
+    G1Affine<E> point;
+    bool operator==(const Commitment& o) const { return point == o.point; }
+};
+template <class E>
+struct UnivariateKzgProof {  // pcs/src/univariate_kzg/mod.rs:49-55
+    G1Affine<E> proof;
+};
+template <class E>
+struct UnivariateProverParam {  // pcs/src/univariate_kzg/srs.rs:40-44
+    std::vector<G1Affine<E>> powers_of_g;
+};
+
+// ark_poly::univariate::DensePolynomial: coefficients, low degree first, no trailing zeros
+struct DensePolynomial {
+    std::vector<Fr> coeffs;
+    static DensePolynomial from_coefficients_vec(std::vector<Fr> c) {
+        while (!c.empty() && is_zero(c.back())) c.pop_back();
+        return DensePolynomial{std::move(c)};
+    }
+    static bool is_zero(const Fr& f) { return (f[0] | f[1] | f[2] | f[3]) == 0; }
+    size_t degree() const { return coeffs.empty() ? 0 : coeffs.size() - 1; }
+};
+
+// ---- errors ---------------------------------------------------------------------------------
+struct PCSError {
+    enum Kind { InvalidParameters, UpstreamError } kind;
+    std::string msg;
+};
+
+template <class T>
+class Result {
+   public:
+    Result(T v) : ok_(true), val_(std::move(v)) {}
+    Result(PCSError e) : ok_(false), err_(std::move(e)) {}
+    bool is_ok() const { return ok_; }
+    bool is_err() const { return !ok_; }
+    T& unwrap() { return val_; }
+    const PCSError& unwrap_err() const { return err_; }
+
+   private:
+    bool ok_;
+    T val_{};
+    PCSError err_{PCSError::UpstreamError, ""};
+};
+
+inline PCSError last_error(int32_t rc) {
+    char buf[600];
+    jfhip_last_error(buf, sizeof(buf));
+    return PCSError{rc == JFHIP_ERR_INVALID ? PCSError::InvalidParameters : PCSError::UpstreamError, buf};
+}
+
+// ---- device objects (RAII, as HostOrDeviceSlice / CudaStream are in the reference) -------------
+class Stream {
+   public:
+    Stream() = default;
+    explicit Stream(jfhip_stream* h) : h_(h) {}
+    Stream(Stream&& o) noexcept : h_(o.h_) { o.h_ = nullptr; }
+    Stream& operator=(Stream&& o) noexcept {
+        reset();
+        h_ = o.h_;
+        o.h_ = nullptr;
+        return *this;
+    }
+    ~Stream() { reset(); }
+    jfhip_stream* get() const { return h_; }
+    Result<bool> synchronize() const {
+        int32_t rc = jfhip_stream_sync(h_);
+        if (rc) return last_error(rc);
+        return true;
+    }
+
+   private:
+    void reset() {
+        if (h_) jfhip_stream_destroy(h_);
+        h_ = nullptr;
+    }
+    jfhip_stream* h_ = nullptr;
+};
+
+// pcs/src/lib.rs:430-435
+inline Result<Stream> warmup_new_stream() {
+    jfhip_stream* h = nullptr;
+    int32_t rc = jfhip_stream_create(&h);
+    if (rc) return last_error(rc);
+    return Stream(h);
+}
+
+template <class E>
+class DeviceSrs {  // HostOrDeviceSlice<IcicleAffine> of load_prover_param_to_gpu
+   public:
+    DeviceSrs() = default;
+    explicit DeviceSrs(jfhip_srs* h) : h_(h) {}
+    DeviceSrs(DeviceSrs&& o) noexcept : h_(o.h_) { o.h_ = nullptr; }
+    DeviceSrs& operator=(DeviceSrs&& o) noexcept {
+        if (h_) jfhip_srs_free(h_);
+        h_ = o.h_;
+        o.h_ = nullptr;
+        return *this;
+    }
+    ~DeviceSrs() {
+        if (h_) jfhip_srs_free(h_);
+    }
+    jfhip_srs* get() const { return h_; }
+    size_t len() const { return jfhip_srs_len(h_); }
+
+   private:
+    jfhip_srs* h_ = nullptr;
+};
+
+// scalars resident on the device (load_poly_to_gpu / load_batch_poly_to_gpu)
+struct DeviceScalars {
+    std::vector<const uint64_t*> ptrs;  // host views; the library stages them per call
+    std::vector<size_t> lens;
+    size_t batch_size = 1;
+};
+
+// device results of commit_on_gpu, before load_commitments_to_host
+template <class E>
+struct DeviceCommitments {
+    std::vector<G1Affine<E>> staged;  // already normalised on the device
+};
+
+// ---- the scheme -------------------------------------------------------------------------------
+template <class E>
+class UnivariateKzgPCS {
+   public:
+    using Polynomial = DensePolynomial;
+    using Point = Fr;
+    using Evaluation = Fr;
+
+    // ===== GPUCommittable<E> =====
+
+    // :767-800
+    static Result<DeviceSrs<E>> load_prover_param_to_gpu(const UnivariateProverParam<E>& pp, size_t supported_degree) {
+        if (pp.powers_of_g.empty() || supported_degree > pp.powers_of_g.size() - 1)
+            return PCSError{PCSError::InvalidParameters,
+                            "supported degree " + std::to_string(supported_degree) + " is larger than allowed " +
+                                std::to_string(pp.powers_of_g.empty() ? 0 : pp.powers_of_g.size() - 1)};
+        jfhip_srs* h = nullptr;
+        int32_t rc = jfhip_srs_load(E::ID, pp.powers_of_g.data(), supported_degree + 1, sizeof(G1Affine<E>), 0, &h);
+        if (rc) return last_error(rc);
+        return DeviceSrs<E>(h);
+    }
+
+    // :804-830 (zero-copy view of the coefficients, as the reference's align_to)
+    static Result<DeviceScalars> load_poly_to_gpu(const Polynomial& poly) {
+        DeviceScalars s;
+        s.ptrs.push_back(poly.coeffs.empty() ? nullptr : poly.coeffs[0].data());
+        s.lens.push_back(poly.coeffs.size());
+        return s;
+    }
+    // :834-879
+    static Result<DeviceScalars> load_batch_poly_to_gpu(const std::vector<Polynomial>& polys) {
+        if (polys.empty()) return PCSError{PCSError::InvalidParameters, "number of polys must be positive"};
+        DeviceScalars s;
+        s.batch_size = polys.size();
+        for (const auto& p : polys) {
+            s.ptrs.push_back(p.coeffs.empty() ? nullptr : p.coeffs[0].data());
+            s.lens.push_back(p.coeffs.size());
+        }
+        return s;
+    }
+
+    // :900-930,1001-1040
+    static Result<DeviceCommitments<E>> commit_on_gpu(DeviceSrs<E>& srs, const DeviceScalars& polys, size_t batch_size,
+                                                      const Stream& stream) {
+        if (batch_size != polys.ptrs.size())
+            return PCSError{PCSError::InvalidParameters, "batch size does not match the loaded polynomials"};
+        constexpr size_t PT = 2 * E::FQ_LIMBS;
+        std::vector<uint64_t> xy(batch_size * PT);
+        std::vector<uint8_t> inf(batch_size);
+        int32_t rc = jfhip_msm_batch(srs.get(), polys.ptrs.data(), polys.lens.data(), batch_size, xy.data(), inf.data(),
+                                     stream.get());
+        if (rc) return last_error(rc);
+        DeviceCommitments<E> out;
+        out.staged.resize(batch_size);
+        for (size_t b = 0; b < batch_size; b++) out.staged[b] = to_affine(xy.data() + b * PT, inf[b]);
+        return out;
+    }
+
+    // :934-964
+    static Result<std::vector<Commitment<E>>> load_commitments_to_host(DeviceCommitments<E> c, const Stream& stream) {
+        auto s = stream.synchronize();
+        if (s.is_err()) return s.unwrap_err();
+        std::vector<Commitment<E>> out;
+        for (auto& p : c.staged) out.push_back(Commitment<E>{p});
+        return out;
+    }
+
+    // :688-699
+    static Result<Commitment<E>> gpu_commit_with_loaded_prover_param(DeviceSrs<E>& srs, const Polynomial& poly,
+                                                                     const Stream& stream) {
+        constexpr size_t PT = 2 * E::FQ_LIMBS;
+        uint64_t xy[PT];
+        uint8_t inf = 0;
+        int32_t rc = jfhip_msm(srs.get(), 0, poly.coeffs.empty() ? nullptr : poly.coeffs[0].data(), poly.coeffs.size(),
+                               xy, &inf, stream.get());
+        if (rc) return last_error(rc);
+        return Commitment<E>{to_affine(xy, inf)};
+    }
+
+    // :664-680
+    static Result<Commitment<E>> gpu_commit(const UnivariateProverParam<E>& pp, const Polynomial& poly) {
+        auto stream = warmup_new_stream();
+        if (stream.is_err()) return stream.unwrap_err();
+        auto srs = load_prover_param_to_gpu(pp, poly.degree());
+        if (srs.is_err()) return srs.unwrap_err();
+        return gpu_commit_with_loaded_prover_param(srs.unwrap(), poly, stream.unwrap());
+    }
+
+    // :731-746
+    static Result<std::vector<Commitment<E>>> gpu_batch_commit_with_loaded_prover_param(
+        DeviceSrs<E>& srs, const std::vector<Polynomial>& polys, const Stream& stream) {
+        if (polys.empty()) return std::vector<Commitment<E>>{};
+        auto loaded = load_batch_poly_to_gpu(polys);
+        if (loaded.is_err()) return loaded.unwrap_err();
+        auto dev = commit_on_gpu(srs, loaded.unwrap(), polys.size(), stream);
+        if (dev.is_err()) return dev.unwrap_err();
+        return load_commitments_to_host(std::move(dev.unwrap()), stream);
+    }
+
+    // :702-727
+    static Result<std::vector<Commitment<E>>> gpu_batch_commit(const UnivariateProverParam<E>& pp,
+                                                               const std::vector<Polynomial>& polys) {
+        if (polys.empty()) return std::vector<Commitment<E>>{};
+        auto stream = warmup_new_stream();
+        if (stream.is_err()) return stream.unwrap_err();
+        size_t degree = 0;
+        for (const auto& p : polys) degree = p.degree() > degree ? p.degree() : degree;
+        auto srs = load_prover_param_to_gpu(pp, degree);
+        if (srs.is_err()) return srs.unwrap_err();
+        return gpu_batch_commit_with_loaded_prover_param(srs.unwrap(), polys, stream.unwrap());
+    }
+
+    // ===== PolynomialCommitmentScheme (routed to the device; the SRS upload is the caller-held
+    // DeviceSrs so that prove() uploads it once) =====
+
+    // :90-125
+    static Result<Commitment<E>> commit(DeviceSrs<E>& srs, const Polynomial& poly) {
+        if (poly.degree() > srs.len())
+            return PCSError{PCSError::InvalidParameters, "poly degree " + std::to_string(poly.degree()) +
+                                                             " is larger than allowed " + std::to_string(srs.len())};
+        // skip_leading_zeros_and_convert_to_bigints (:1044-1053): drop low-order zero coefficients
+        size_t z = 0;
+        while (z < poly.coeffs.size() && DensePolynomial::is_zero(poly.coeffs[z])) z++;
+        constexpr size_t PT = 2 * E::FQ_LIMBS;
+        uint64_t xy[PT];
+        uint8_t inf = 0;
+        size_t n = poly.coeffs.size() - z;
+        int32_t rc = jfhip_msm(srs.get(), z, n ? poly.coeffs[z].data() : nullptr, n, xy, &inf, nullptr);
+        if (rc) return last_error(rc);
+        return Commitment<E>{to_affine(xy, inf)};
+    }
+    // :128-140
+    static Result<std::vector<Commitment<E>>> batch_commit(DeviceSrs<E>& srs, const std::vector<Polynomial>& polys) {
+        Stream none;
+        return gpu_batch_commit_with_loaded_prover_param(srs, polys, none);
+    }
+    // :144-180
+    static Result<std::pair<UnivariateKzgProof<E>, Evaluation>> open(DeviceSrs<E>& srs, const Polynomial& poly,
+                                                                     const Point& point) {
+        constexpr size_t PT = 2 * E::FQ_LIMBS;
+        uint64_t xy[PT];
+        uint8_t inf = 0;
+        Fr eval{};
+        int32_t rc = jfhip_kzg_open(srs.get(), poly.coeffs.empty() ? nullptr : poly.coeffs[0].data(), poly.coeffs.size(),
+                                    point.data(), xy, &inf, eval.data(), nullptr);
+        if (rc) return last_error(rc);
+        return std::make_pair(UnivariateKzgProof<E>{to_affine(xy, inf)}, eval);
+    }
+    // :187-211
+    static Result<std::pair<std::vector<UnivariateKzgProof<E>>, std::vector<Evaluation>>> batch_open(
+        DeviceSrs<E>& srs, const std::vector<Polynomial>& polys, const std::vector<Point>& points) {
+        if (polys.size() != points.size())
+            return PCSError{PCSError::InvalidParameters, "poly length " + std::to_string(polys.size()) +
+                                                             " is different from points length " +
+                                                             std::to_string(points.size())};
+        std::vector<UnivariateKzgProof<E>> proofs;
+        std::vector<Evaluation> evals;
+        for (size_t i = 0; i < polys.size(); i++) {
+            auto r = open(srs, polys[i], points[i]);
+            if (r.is_err()) return r.unwrap_err();
+            proofs.push_back(r.unwrap().first);
+            evals.push_back(r.unwrap().second);
+        }
+        return std::make_pair(std::move(proofs), std::move(evals));
+    }
+
+   private:
+    // icicle_projective_to_ark (:982-998): identity -> G1Affine::zero()
+    static G1Affine<E> to_affine(const uint64_t* xy, uint8_t inf) {
+        if (inf) return G1Affine<E>::zero();
+        G1Affine<E> p;
+        std::memcpy(p.x.data(), xy, sizeof(p.x));
+        std::memcpy(p.y.data(), xy + E::FQ_LIMBS, sizeof(p.y));
+        p.infinity = false;
+        return p;
+    }
+};
+
+// ---- evaluation domain --------------------------------------------------------------------------
+template <class E>
+class Radix2EvaluationDomain {
+   public:
+    // Radix2EvaluationDomain::new(num_coeffs): size = next power of two, None beyond the two-adicity
+    static Result<Radix2EvaluationDomain> create(size_t num_coeffs) {
+        uint32_t log_size = 0;
+        while (((size_t)1 << log_size) < num_coeffs) log_size++;
+        if (log_size > E::TWO_ADICITY) return PCSError{PCSError::InvalidParameters, "domain size exceeds the two-adicity"};
+        Radix2EvaluationDomain d;
+        d.log_size_ = log_size;
+        return d;
+    }
+    size_t size() const { return (size_t)1 << log_size_; }
+    uint32_t log_size_of_group() const { return log_size_; }
+
+    // get_coset(offset): offset as a Montgomery field element (the prover passes Fr::GENERATOR)
+    Radix2EvaluationDomain get_coset(const Fr& offset_mont) const {
+        Radix2EvaluationDomain d = *this;
+        d.has_offset_ = true;
+        d.offset_ = offset_mont;
+        return d;
+    }
+
+    // fft(&coeffs): evaluations in natural order; short inputs are zero-extended
+    Result<std::vector<Fr>> fft(const std::vector<Fr>& coeffs) const { return transform(coeffs, 0); }
+    Result<std::vector<Fr>> ifft(const std::vector<Fr>& evals) const { return transform(evals, 1); }
+    Result<bool> fft_in_place(std::vector<Fr>& v) const { return in_place(v, 0); }
+    Result<bool> ifft_in_place(std::vector<Fr>& v) const { return in_place(v, 1); }
+
+    // many polynomials of one domain in one call (the prover's rayon loops at
+    // prover.rs:534-544, constraint_system.rs:1368,1383,1433); data = batch * size() elements
+    Result<bool> batch_in_place(std::vector<Fr>& data, size_t batch, int inverse, size_t in_len = 0) const {
+        if (data.size() != batch * size()) return PCSError{PCSError::InvalidParameters, "batch data size mismatch"};
+        int32_t rc = jfhip_ntt(E::ID, data.empty() ? nullptr : data[0].data(), log_size_, batch, inverse,
+                               has_offset_ ? offset_.data() : nullptr, in_len, nullptr);
+        if (rc) return last_error(rc);
+        return true;
+    }
+
+   private:
+    Result<bool> in_place(std::vector<Fr>& v, int inverse) const {
+        if (v.size() > size()) return PCSError{PCSError::InvalidParameters, "input longer than the domain"};
+        size_t in_len = v.size();
+        v.resize(size(), Fr{0, 0, 0, 0});
+        return batch_in_place(v, 1, inverse, in_len);
+    }
+    Result<std::vector<Fr>> transform(const std::vector<Fr>& in, int inverse) const {
+        std::vector<Fr> v = in;
+        auto r = in_place(v, inverse);
+        if (r.is_err()) return r.unwrap_err();
+        return v;
+    }
+    uint32_t log_size_ = 0;
+    bool has_offset_ = false;
+    Fr offset_{};
+};
+
+}  // namespace jf_pcs
