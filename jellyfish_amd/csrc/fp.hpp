@@ -282,39 +282,69 @@ JF_DEV void jf_mac_s(uint64_t& lo, uint32_t& hi, uint32_t a, uint32_t b_uniform)
         : "vcc");
 }
 
+#define JF_MAC_TXT(A, B) "v_mad_u64_u32 %0, vcc, %" #A ", %" #B ", %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+// K (a*b, m*p) pairs of one column in ONE asm statement: hipcc pads an s_nop after every asm
+// statement that feeds the next one, so fewer, longer statements issue fewer bubbles.
+template <class C, int I, int J, int CNT>
+JF_DEV void jf_col_pairs(uint64_t& lo, uint32_t& hi, const uint32_t* a, const uint32_t* b, const uint32_t* m) {
+    if constexpr (CNT >= 4) {
+        asm(JF_MAC_TXT(2, 3) JF_MAC_TXT(4, 5) JF_MAC_TXT(6, 7) JF_MAC_TXT(8, 9) JF_MAC_TXT(10, 11) JF_MAC_TXT(12, 13)
+                JF_MAC_TXT(14, 15) JF_MAC_TXT(16, 17)
+            : "+v"(lo), "+v"(hi)
+            : "v"(a[J]), "v"(b[I - J]), "v"(m[J]), "s"(C::P(I - J)), "v"(a[J + 1]), "v"(b[I - J - 1]), "v"(m[J + 1]),
+              "s"(C::P(I - J - 1)), "v"(a[J + 2]), "v"(b[I - J - 2]), "v"(m[J + 2]), "s"(C::P(I - J - 2)),
+              "v"(a[J + 3]), "v"(b[I - J - 3]), "v"(m[J + 3]), "s"(C::P(I - J - 3))
+            : "vcc");
+        jf_col_pairs<C, I, J + 4, CNT - 4>(lo, hi, a, b, m);
+    } else if constexpr (CNT >= 2) {
+        asm(JF_MAC_TXT(2, 3) JF_MAC_TXT(4, 5) JF_MAC_TXT(6, 7) JF_MAC_TXT(8, 9)
+            : "+v"(lo), "+v"(hi)
+            : "v"(a[J]), "v"(b[I - J]), "v"(m[J]), "s"(C::P(I - J)), "v"(a[J + 1]), "v"(b[I - J - 1]), "v"(m[J + 1]),
+              "s"(C::P(I - J - 1))
+            : "vcc");
+        jf_col_pairs<C, I, J + 2, CNT - 2>(lo, hi, a, b, m);
+    } else if constexpr (CNT == 1) {
+        asm(JF_MAC_TXT(2, 3) JF_MAC_TXT(4, 5)
+            : "+v"(lo), "+v"(hi)
+            : "v"(a[J]), "v"(b[I - J]), "v"(m[J]), "s"(C::P(I - J))
+            : "vcc");
+    }
+}
+
+template <class C, int I>
+JF_DEV void jf_fips_low(uint64_t& lo, uint32_t& hi, const uint32_t* a, const uint32_t* b, uint32_t* m) {
+    if constexpr (I < C::N) {
+        jf_col_pairs<C, I, 0, I>(lo, hi, a, b, m);
+        jf_mac(lo, hi, a[I], b[0]);
+        m[I] = (uint32_t)lo * C::INV;
+        jf_mac_s(lo, hi, m[I], C::P(0));
+        lo = (lo >> 32) | ((uint64_t)hi << 32);
+        hi = 0;
+        jf_fips_low<C, I + 1>(lo, hi, a, b, m);
+    }
+}
+template <class C, int I>
+JF_DEV void jf_fips_high(uint64_t& lo, uint32_t& hi, const uint32_t* a, const uint32_t* b, const uint32_t* m,
+                         uint32_t* r) {
+    if constexpr (I < 2 * C::N) {
+        jf_col_pairs<C, I, I - C::N + 1, 2 * C::N - 1 - I>(lo, hi, a, b, m);
+        r[I - C::N] = (uint32_t)lo;
+        lo = (lo >> 32) | ((uint64_t)hi << 32);
+        hi = 0;
+        jf_fips_high<C, I + 1>(lo, hi, a, b, m, r);
+    }
+}
+
 // Montgomery product, finely integrated product scanning (FIPS): column i of a*b + m*p is summed
 // in one 96-bit accumulator, m[i] is chosen to clear its low word, the accumulator shifts down.
 template <class C>
 JF_DEV Fp<C> fp_mul(const Fp<C>& a, const Fp<C>& b) {
-    constexpr int N = C::N;
-    uint32_t m[N];
+    uint32_t m[C::N];
     Fp<C> r;
     uint64_t lo = 0;
     uint32_t hi = 0;
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-#pragma unroll
-        for (int j = 0; j < i; j++) {
-            jf_mac(lo, hi, a.v[j], b.v[i - j]);
-            jf_mac_s(lo, hi, m[j], C::P(i - j));
-        }
-        jf_mac(lo, hi, a.v[i], b.v[0]);
-        m[i] = (uint32_t)lo * C::INV;
-        jf_mac_s(lo, hi, m[i], C::P(0));
-        lo = (lo >> 32) | ((uint64_t)hi << 32);
-        hi = 0;
-    }
-#pragma unroll
-    for (int i = N; i < 2 * N; i++) {
-#pragma unroll
-        for (int j = i - N + 1; j < N; j++) {
-            jf_mac(lo, hi, a.v[j], b.v[i - j]);
-            jf_mac_s(lo, hi, m[j], C::P(i - j));
-        }
-        r.v[i - N] = (uint32_t)lo;
-        lo = (lo >> 32) | ((uint64_t)hi << 32);
-        hi = 0;
-    }
+    jf_fips_low<C, 0>(lo, hi, a.v, b.v, m);
+    jf_fips_high<C, C::N>(lo, hi, a.v, b.v, m, r.v);
     return fp_reduce_once<C>(r);
 }
 #else
