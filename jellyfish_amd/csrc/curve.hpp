@@ -132,9 +132,9 @@ JF_HD void xyzz_add_affine(XYZZ<Cv>& acc, const Affine<Cv>& q) {
     acc.ZZZ = fp_mul<Q>(acc.ZZZ, PPP);
 }
 
-// acc += q   (EFD add-2008-s)
+// acc += q   (EFD add-2008-s).  Body shared by the out-of-line and the inline entry points.
 template <class Cv>
-JF_COLD void xyzz_add(XYZZ<Cv>& acc, const XYZZ<Cv>& q) {
+JF_HD void xyzz_add_body(XYZZ<Cv>& acc, const XYZZ<Cv>& q) {
     using Q = typename Cv::Fq;
     if (q.is_inf()) return;
     if (acc.is_inf()) {
@@ -148,8 +148,11 @@ JF_COLD void xyzz_add(XYZZ<Cv>& acc, const XYZZ<Cv>& q) {
     auto P = fp_sub<Q>(U2, U1);
     auto R = fp_sub<Q>(S2, S1);
     if (P.is_zero()) {
-        if (R.is_zero()) acc = xyzz_double<Cv>(acc);
-        else acc = XYZZ<Cv>::identity();
+        if (R.is_zero()) {
+            XYZZ<Cv> ac = acc;
+            XYZZ<Cv> d = xyzz_double<Cv>(ac);
+            acc = d;
+        } else acc = XYZZ<Cv>::identity();
         return;
     }
     auto PP = fp_sqr<Q>(P);
@@ -162,6 +165,16 @@ JF_COLD void xyzz_add(XYZZ<Cv>& acc, const XYZZ<Cv>& q) {
     acc.ZZ = fp_mul<Q>(fp_mul<Q>(acc.ZZ, q.ZZ), PP);
     acc.ZZZ = fp_mul<Q>(fp_mul<Q>(acc.ZZZ, q.ZZZ), PPP);
 }
+// out of line: cold call sites (keeps code size and compile time down)
+template <class Cv>
+JF_COLD void xyzz_add(XYZZ<Cv>& acc, const XYZZ<Cv>& q) {
+    xyzz_add_body<Cv>(acc, q);
+}
+// inline: the latency-bound reduction kernels, where a call's scratch round trip is visible
+template <class Cv>
+JF_DEV void xyzz_add_inl(XYZZ<Cv>& acc, const XYZZ<Cv>& q) {
+    xyzz_add_body<Cv>(acc, q);
+}
 
 // exact affine normalisation: one field inversion
 template <class Cv>
@@ -173,7 +186,7 @@ JF_COLD Affine<Cv> xyzz_to_affine(const XYZZ<Cv>& p) {
         r.y = Fp<Q>::zero();
         return r;
     }
-    auto t = fp_inv<Q>(fp_mul<Q>(p.ZZ, p.ZZZ));
+    auto t = fp_inv_binary<Q>(fp_mul<Q>(p.ZZ, p.ZZZ));
     r.x = fp_mul<Q>(p.X, fp_mul<Q>(t, p.ZZZ));
     r.y = fp_mul<Q>(p.Y, fp_mul<Q>(t, p.ZZ));
     return r;

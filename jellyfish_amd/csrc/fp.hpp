@@ -421,6 +421,101 @@ __device__ __noinline__ Fp<C> fp_inv(const Fp<C>& a) {
     return acc;
 }
 
+// Binary extended Euclid on the raw integers (HAC 14.61 shape): ~2*bits iterations of shifts and
+// subtractions instead of ~1.5*bits Montgomery products -- about 4x faster than the Fermat ladder
+// for the one-lane normalisation at the end of every MSM.  Input/output in Montgomery form:
+// inv(aR) = a^-1 R^-1, lifted back with two multiplications by R^2.  inv(0) = 0.
+template <class C>
+__device__ __noinline__ Fp<C> fp_inv_binary(const Fp<C>& a) {
+    constexpr int N = C::N;
+    if (a.is_zero()) return a;
+    uint32_t u[N], v[N], x1[N], x2[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        u[i] = a.v[i];
+        v[i] = C::P(i);
+        x1[i] = (i == 0) ? 1u : 0u;
+        x2[i] = 0u;
+    }
+    auto is_one = [](const uint32_t* w) {
+        uint32_t t = w[0] ^ 1u;
+#pragma unroll
+        for (int i = 1; i < N; i++) t |= w[i];
+        return t == 0;
+    };
+    auto shr1 = [](uint32_t* w, uint32_t top) {
+#pragma unroll
+        for (int i = 0; i < N - 1; i++) w[i] = (w[i] >> 1) | (w[i + 1] << 31);
+        w[N - 1] = (w[N - 1] >> 1) | (top << 31);
+    };
+    auto half_mod = [&](uint32_t* x) {  // x/2 mod p
+        uint32_t carry = 0;
+        if (x[0] & 1u) {
+#pragma unroll
+            for (int i = 0; i < N; i++) {
+                uint64_t t = (uint64_t)x[i] + C::P(i) + carry;
+                x[i] = (uint32_t)t;
+                carry = (uint32_t)(t >> 32);
+            }
+        }
+        shr1(x, carry);
+    };
+    auto geq = [](const uint32_t* p1, const uint32_t* p2) {
+        uint32_t borrow = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            uint64_t d = (uint64_t)p1[i] - p2[i] - borrow;
+            borrow = (uint32_t)(d >> 32) & 1u;
+        }
+        return borrow == 0;
+    };
+    auto sub_raw = [](uint32_t* p1, const uint32_t* p2) {  // p1 -= p2
+        uint32_t borrow = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            uint64_t d = (uint64_t)p1[i] - p2[i] - borrow;
+            p1[i] = (uint32_t)d;
+            borrow = (uint32_t)(d >> 32) & 1u;
+        }
+        return borrow;
+    };
+    auto sub_mod = [&](uint32_t* p1, const uint32_t* p2) {  // p1 = p1 - p2 mod p
+        if (sub_raw(p1, p2)) {
+            uint32_t carry = 0;
+#pragma unroll
+            for (int i = 0; i < N; i++) {
+                uint64_t t = (uint64_t)p1[i] + C::P(i) + carry;
+                p1[i] = (uint32_t)t;
+                carry = (uint32_t)(t >> 32);
+            }
+        }
+    };
+    // bounded: each pass of the outer loop strips at least one bit of u or v
+    for (int guard = 0; guard < 4 * 32 * N && !is_one(u) && !is_one(v); guard++) {
+        while (!(u[0] & 1u)) {
+            shr1(u, 0);
+            half_mod(x1);
+        }
+        while (!(v[0] & 1u)) {
+            shr1(v, 0);
+            half_mod(x2);
+        }
+        if (geq(u, v)) {
+            sub_raw(u, v);
+            sub_mod(x1, x2);
+        } else {
+            sub_raw(v, u);
+            sub_mod(x2, x1);
+        }
+    }
+    Fp<C> r;
+    const bool pick_u = is_one(u);
+#pragma unroll
+    for (int i = 0; i < N; i++) r.v[i] = pick_u ? x1[i] : x2[i];
+    r = fp_mul<C>(r, Fp<C>::r2());
+    return fp_mul<C>(r, Fp<C>::r2());
+}
+
 // small-exponent power
 template <class C>
 JF_HD Fp<C> fp_pow_u64(Fp<C> base, uint64_t e) {

@@ -390,7 +390,7 @@ __global__ __launch_bounds__(128) void k_msm_fixup(const uint32_t* __restrict__ 
     XYZZ<Cv> acc = xyzz_load<Cv>(((s % L == 0) ? partA : partB) + (size_t)t1 * XZ);
     for (uint32_t t = t1 + 1; t <= t2; t++) {
         XYZZ<Cv> q = xyzz_load<Cv>(partA + (size_t)t * XZ);
-        xyzz_add<Cv>(acc, q);
+        xyzz_add_inl<Cv>(acc, q);
     }
     xyzz_store<Cv>(buckets + (size_t)b * XZ, acc);
 }
@@ -417,8 +417,8 @@ __global__ __launch_bounds__(64) void k_msm_bucket_fold(const uint32_t* __restri
     XYZZ<Cv> run = XYZZ<Cv>::identity(), sum = XYZZ<Cv>::identity();
     for (uint32_t j = hi; j-- > lo;) {
         XYZZ<Cv> q = xyzz_load<Cv>(buckets + (size_t)j * XZ);
-        xyzz_add<Cv>(run, q);
-        xyzz_add<Cv>(sum, run);
+        xyzz_add_inl<Cv>(run, q);
+        xyzz_add_inl<Cv>(sum, run);
     }
     if (lo) {
         XYZZ<Cv> sh = xyzz_mul_small<Cv>(run, lo);
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(256) void k_g1_sum(const uint32_t* __restrict__ in,
         uint32_t idx = base + k * 256u + threadIdx.x;
         if (idx < m) {
             XYZZ<Cv> q = xyzz_load<Cv>(in + (size_t)idx * XZ);
-            xyzz_add<Cv>(acc, q);
+            xyzz_add_inl<Cv>(acc, q);
         }
     }
     xyzz_store<Cv>(sh + threadIdx.x * XZ, acc);
@@ -447,7 +447,7 @@ __global__ __launch_bounds__(256) void k_g1_sum(const uint32_t* __restrict__ in,
     for (uint32_t s = 128; s > 0; s >>= 1) {
         if (threadIdx.x < s) {
             XYZZ<Cv> q = xyzz_load<Cv>(sh + (threadIdx.x + s) * XZ);
-            xyzz_add<Cv>(acc, q);
+            xyzz_add_inl<Cv>(acc, q);
             xyzz_store<Cv>(sh + threadIdx.x * XZ, acc);
         }
         __syncthreads();
@@ -795,8 +795,8 @@ static int32_t msm_partial_t(const jfhip_srs* srs, size_t offset, const uint32_t
     JF_TRY(st->bsum.ensure(((size_t)nb + 1) * 4));
     JF_TRY(st->buckets.ensure((size_t)B * XZ * 4));
     // fold: g buckets per lane, then a sum tree (the fold output reuses partA after the fix-up)
-    uint32_t g = 16;
-    if (B < 4096) g = 4;
+    // latency-bound for small bucket counts (few lanes, deep chains): short chains there
+    uint32_t g = (B <= (1u << 17)) ? 4 : 16;
     const uint32_t Tf = (B + g - 1) / g;
     JF_TRY(st->partA.ensure((T > Tf ? T : Tf) * XZ * 4));
     JF_TRY(st->partB.ensure(T * XZ * 4));
