@@ -156,6 +156,23 @@ int32_t jfhip_ntt(int32_t curve_id, uint64_t *data, uint32_t log_n, size_t batch
 int32_t jfhip_ntt_device(int32_t curve_id, void *d_data, uint32_t log_n, size_t batch, int32_t inverse,
                          const uint64_t *coset_offset_mont, size_t in_len, jfhip_stream *stream);
 
+/* ---- PLONK quotient evaluations (next row of the path) ----------------- */
+
+/* Replaces the per-point loop of Prover::compute_quotient_polynomial
+ * (plonk/src/proof_system/prover.rs:587-655, gate part :665-699, copy-constraint part :709-752)
+ * for one TurboPlonk instance (5 wire types, 13 selectors, no Plookup):
+ *     d_quot[i] += alpha_base * ((t_circ + t_perm_1) * z_h_inv[i mod (m/n)] + t_perm_2)
+ * All inputs are DEVICE arrays of coset evaluations over the size-2^log_m quotient domain with
+ * offset Fr::GENERATOR (what jfhip_ntt_device leaves), laid out [poly][2^log_m]:
+ * d_selectors 13 polys in the reference's order (q_lc[4], q_mul[2], q_hash[4], q_o, q_c, q_ecc),
+ * d_sigmas 5, d_wires 5, d_prod_perm 1, d_pub_input 1.  k_mont: the 5 coset representatives
+ * pk.k(); challenges_mont: alpha, beta, gamma, alpha_base (4 x 4 limbs), all host, Montgomery.
+ * d_quot is accumulated into (zero it for the first instance).  Asynchronous on `stream`. */
+int32_t jfhip_plonk_quotient_turbo_device(int32_t curve_id, uint32_t log_n, uint32_t log_m, const void *d_selectors,
+                                          const void *d_sigmas, const void *d_wires, const void *d_prod_perm,
+                                          const void *d_pub_input, const uint64_t *k_mont,
+                                          const uint64_t *challenges_mont, void *d_quot, jfhip_stream *stream);
+
 /* ---- field / group vector ops (test and glue surface) -------------------------------------- */
 
 /* field_id: 0 BN254 Fr, 1 BN254 Fq, 2 BLS12-381 Fr, 3 BLS12-381 Fq.

@@ -91,7 +91,7 @@ jfhip_stream* resolve_stream(jfhip_stream* s) {
 static void stream_release(jfhip_stream* s) {
     DevBuf* bufs[] = {&s->scalars, &s->dig, &s->dig2, &s->midbase, &s->midcnt, &s->midcur, &s->finecnt, &s->finecur, &s->sorted, &s->counts, &s->offs,   &s->cursor, &s->bsum,
                       &s->buckets, &s->partA, &s->partB, &s->red0,   &s->red1,   &s->result, &s->ntt_tmp,
-                      &s->ntt_io,  &s->poly_a, &s->poly_b, &s->poly_c};
+                      &s->ntt_io,  &s->poly_a, &s->poly_b, &s->poly_c, &s->quot_consts};
     for (DevBuf* b : bufs) b->release();
     if (s->ev_ready)
         for (int i = 0; i <= MAX_PHASES; i++) (void)hipEventDestroy(s->ev[i]);
@@ -542,6 +542,22 @@ int32_t jfhip_ntt(int32_t curve_id, uint64_t* data, uint32_t log_n, size_t batch
     JF_HIP(hipMemcpyAsync(data, st->ntt_io.p, bytes, hipMemcpyDeviceToHost, st->s));
     JF_HIP(hipStreamSynchronize(st->s));
     return JFHIP_OK;
+}
+
+int32_t jfhip_plonk_quotient_turbo_device(int32_t curve_id, uint32_t log_n, uint32_t log_m, const void* d_sel,
+                                          const void* d_sig, const void* d_wires, const void* d_zperm,
+                                          const void* d_pi, const uint64_t* k_mont, const uint64_t* ch, void* d_quot,
+                                          jfhip_stream* stream) {
+    JF_TRY(check_curve(curve_id));
+    if (!d_sel || !d_sig || !d_wires || !d_zperm || !d_pi || !k_mont || !ch || !d_quot) {
+        set_error("null argument");
+        return JFHIP_ERR_INVALID;
+    }
+    JF_STREAM(st, stream);
+    std::lock_guard<std::mutex> lk(st->mu);
+    return plonk_quotient_turbo_device(curve_id, log_n, log_m, (const uint32_t*)d_sel, (const uint32_t*)d_sig,
+                                       (const uint32_t*)d_wires, (const uint32_t*)d_zperm, (const uint32_t*)d_pi,
+                                       k_mont, ch, (uint32_t*)d_quot, st);
 }
 
 // ---- field / group test surface ---------------------------------------------------------------------

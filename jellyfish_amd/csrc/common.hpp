@@ -54,7 +54,7 @@ struct jfhip_stream {
     // NTT workspace
     jf::DevBuf ntt_tmp, ntt_io;
     // open()
-    jf::DevBuf poly_a, poly_b, poly_c;
+    jf::DevBuf poly_a, poly_b, poly_c, quot_consts;
     // phase timing
     hipEvent_t ev[jf::MAX_PHASES + 1] = {};
     bool ev_ready = false;
@@ -96,6 +96,12 @@ int32_t srs_pack_points(int32_t curve, const uint8_t* d_raw, size_t n, size_t st
                         jfhip_stream* st);
 int32_t ntt_device(int32_t curve, uint32_t* d_data, uint32_t log_n, size_t batch, int inverse,
                    const uint64_t* coset_mont, size_t in_len, jfhip_stream* st);
+int32_t ntt_root_tables(int32_t curve, uint32_t log_n, const uint32_t** lo, const uint32_t** hi, uint32_t* a,
+                        jfhip_stream* st);
+int32_t plonk_quotient_turbo_device(int32_t curve, uint32_t log_n, uint32_t log_m, const uint32_t* sel,
+                                    const uint32_t* sig, const uint32_t* wires, const uint32_t* zperm,
+                                    const uint32_t* pi, const uint64_t* k_mont, const uint64_t* challenges_mont,
+                                    uint32_t* out, jfhip_stream* st);
 int32_t open_witness_device(int32_t curve, const uint32_t* d_coeffs, size_t n, const uint32_t* d_point,
                             uint32_t* d_witness, uint32_t* d_eval, jfhip_stream* st);
 int32_t field_op_device(int32_t field_id, int32_t op, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t n,

@@ -306,6 +306,39 @@ static int32_t build_tables(uint32_t log_n, int inverse, const uint64_t* coset_m
     return JFHIP_OK;
 }
 
+// cached per (device, curve, log_n, direction, coset)
+template <class Fr>
+static int32_t get_tables(int32_t curve, uint32_t log_n, int inverse, const uint64_t* coset_mont, NttTables* out,
+                          jfhip_stream* st) {
+    TableKey key;
+    memset(&key, 0, sizeof(key));
+    JF_HIP(hipGetDevice(&key.device));
+    key.curve = curve;
+    key.inverse = inverse ? 1 : 0;
+    key.has_coset = coset_mont ? 1 : 0;
+    key.log_n = log_n;
+    if (coset_mont) memcpy(key.coset, coset_mont, 32);
+    std::lock_guard<std::mutex> lk(g_tab_mu);
+    auto it = g_tables.find(key);
+    if (it == g_tables.end()) {
+        JF_TRY(build_tables<Fr>(log_n, inverse ? 1 : 0, coset_mont, out, st));
+        g_tables[key] = *out;
+    } else *out = it->second;
+    return JFHIP_OK;
+}
+
+// two-level table of the forward domain generator: w^e = lo[e mod 2^a] * hi[e >> a]
+int32_t ntt_root_tables(int32_t curve, uint32_t log_n, const uint32_t** lo, const uint32_t** hi, uint32_t* a,
+                        jfhip_stream* st) {
+    NttTables t;
+    if (curve == JFHIP_BN254) JF_TRY(get_tables<Bn254Fr>(curve, log_n, 0, nullptr, &t, st));
+    else JF_TRY(get_tables<Bls381Fr>(curve, log_n, 0, nullptr, &t, st));
+    *lo = t.tl;
+    *hi = t.th;
+    *a = t.a;
+    return JFHIP_OK;
+}
+
 template <class Fr>
 static int32_t ntt_device_t(int32_t curve, uint32_t* d_data, uint32_t log_n, size_t batch, int inverse,
                             const uint64_t* coset_mont, size_t in_len, jfhip_stream* st) {
@@ -336,22 +369,7 @@ static int32_t ntt_device_t(int32_t curve, uint32_t* d_data, uint32_t log_n, siz
     }
     PhaseTimer pt(st, 1);
     NttTables tabs;
-    {
-        TableKey key;
-        memset(&key, 0, sizeof(key));
-        JF_HIP(hipGetDevice(&key.device));
-        key.curve = curve;
-        key.inverse = inverse ? 1 : 0;
-        key.has_coset = coset_mont ? 1 : 0;
-        key.log_n = log_n;
-        if (coset_mont) memcpy(key.coset, coset_mont, 32);
-        std::lock_guard<std::mutex> lk(g_tab_mu);
-        auto it = g_tables.find(key);
-        if (it == g_tables.end()) {
-            JF_TRY(build_tables<Fr>(log_n, inverse ? 1 : 0, coset_mont, &tabs, st));
-            g_tables[key] = tabs;
-        } else tabs = it->second;
-    }
+    JF_TRY(get_tables<Fr>(curve, log_n, inverse ? 1 : 0, coset_mont, &tabs, st));
     // digit plan
     uint32_t ndig = (log_n + NTT_MAX_DIGIT - 1) / NTT_MAX_DIGIT;
     uint32_t dig[4] = {0, 0, 0, 0};

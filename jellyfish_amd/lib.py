@@ -35,7 +35,7 @@ SYMBOLS = [
     "jfhip_stream_sync", "jfhip_stream_raw", "jfhip_stream_wrap", "jfhip_srs_load", "jfhip_srs_load_device",
     "jfhip_srs_gen_for_testing", "jfhip_srs_free", "jfhip_srs_len", "jfhip_srs_window_bits", "jfhip_srs_read",
     "jfhip_msm", "jfhip_msm_batch", "jfhip_msm_device", "jfhip_msm_partial_device", "jfhip_g1_sum_partials",
-    "jfhip_kzg_open", "jfhip_ntt", "jfhip_ntt_device", "jfhip_field_op", "jfhip_g1_op", "jfhip_probe",
+    "jfhip_kzg_open", "jfhip_ntt", "jfhip_ntt_device", "jfhip_plonk_quotient_turbo_device", "jfhip_field_op", "jfhip_g1_op", "jfhip_probe",
     "jfhip_set_profiling", "jfhip_last_phase_ms", "jfhip_phase_name",
 ]
 
@@ -252,6 +252,17 @@ def ntt_device(curve: int, d_data: int, log_n: int, batch: int, inverse: bool = 
     cs = _u64(coset_mont) if coset_mont is not None else None
     _check(load_library().jfhip_ntt_device(curve, _vp(d_data), log_n, ctypes.c_size_t(batch), int(bool(inverse)),
                                            _p(cs) if cs is not None else None, ctypes.c_size_t(in_len), _sh(stream)))
+
+
+def plonk_quotient_turbo_device(curve: int, log_n: int, log_m: int, d_selectors: int, d_sigmas: int, d_wires: int,
+                                d_prod_perm: int, d_pub_input: int, k_mont, challenges_mont, d_quot: int,
+                                stream: Stream | None = None):
+    """TurboPlonk quotient evaluations on device arrays (see include/jfhip.h)."""
+    k, ch = _u64(k_mont), _u64(challenges_mont)
+    assert k.size == 20 and ch.size == 16
+    _check(load_library().jfhip_plonk_quotient_turbo_device(curve, log_n, log_m, _vp(d_selectors), _vp(d_sigmas),
+                                                            _vp(d_wires), _vp(d_prod_perm), _vp(d_pub_input), _p(k),
+                                                            _p(ch), _vp(d_quot), _sh(stream)))
 
 
 FIELD_OPS = {"add": 0, "sub": 1, "mul": 2, "neg": 3, "inv": 4, "from_mont": 5, "to_mont": 6}

@@ -34,7 +34,7 @@ def lib():
         _LIB = ctypes.CDLL(so)
         for name in ("jfo_fp_binop", "jfo_fp_unop", "jfo_ec_add", "jfo_ec_mul", "jfo_ec_on_curve", "jfo_srs_gen",
                      "jfo_msm", "jfo_msm_naive", "jfo_poly_eval", "jfo_open_witness", "jfo_ntt", "jfo_domain_root",
-                     "jfo_threads", "jfo_field_limbs"):
+                     "jfo_threads", "jfo_field_limbs", "jfo_plonk_quotient_turbo"):
             getattr(_LIB, name).restype = ctypes.c_int
     return _LIB
 
@@ -144,6 +144,20 @@ def ntt(curve: int, data, log_n: int, inverse: bool = False, coset_mont=None, th
     assert lib().jfo_ntt(curve, _p(d), log_n, ctypes.c_size_t(batch), int(bool(inverse)), cp,
                          threads or nthreads()) == 0
     return d
+
+
+def plonk_quotient_turbo(curve: int, log_n: int, log_m: int, sel, sig, wires, zperm, pi, k, alpha, beta, gamma,
+                         alpha_base, out=None, threads: int = 0):
+    """arrays [poly][m][4] uint64 Montgomery; returns out (+= alpha_base * t)."""
+    m = 1 << log_m
+    sel, sig, wires, zperm, pi = (_u64(x) for x in (sel, sig, wires, zperm, pi))
+    assert sel.size == 13 * m * 4 and sig.size == 5 * m * 4 and wires.size == 5 * m * 4
+    k, alpha, beta, gamma, alpha_base = (_u64(x) for x in (k, alpha, beta, gamma, alpha_base))
+    o = np.zeros((m, 4), dtype=np.uint64) if out is None else np.array(out, dtype=np.uint64, copy=True)
+    assert lib().jfo_plonk_quotient_turbo(curve, log_n, log_m, 5, _p(sel), _p(sig), _p(wires), _p(zperm), _p(pi), _p(k),
+                                          _p(alpha), _p(beta), _p(gamma), _p(alpha_base), _p(o),
+                                          threads or nthreads()) == 0
+    return o
 
 
 def domain_root(curve: int, log_n: int):

@@ -491,3 +491,107 @@ int jfo_ntt(int curve, uint64_t *data, int log_n, size_t batch, int inverse, con
 }
 
 int jfo_threads(void) { return omp_get_max_threads(); }
+
+/* ---- TurboPlonk quotient evaluations -----------------------------------
+ * Restates plonk/src/proof_system/prover.rs:587-655 with :665-699 (gate part) and :709-752
+ * (copy-constraint part) for one instance without Plookup:
+ *   t_i = (t_circ + t_perm_1) * z_h_inv[i % ratio] + t_perm_2,   out[i] += alpha_base * t_i
+ * All arrays are coset evaluations over the size-m quotient domain (coset offset = Fr::GENERATOR),
+ * laid out [poly][m]; 13 selectors in the reference's order q_lc[4], q_mul[2], q_hash[4], q_o, q_c,
+ * q_ecc; nw wire types (5); k[nw] coset representatives; every element Montgomery. */
+int jfo_plonk_quotient_turbo(int curve, int log_n, int log_m, int nw, const uint64_t *sel, const uint64_t *sig,
+                             const uint64_t *wires, const uint64_t *zperm, const uint64_t *pi, const uint64_t *k,
+                             const uint64_t *alpha, const uint64_t *beta, const uint64_t *gamma,
+                             const uint64_t *alpha_base, uint64_t *out, int threads) {
+    ensure_init();
+    if ((curve != 0 && curve != 1) || nw != 5 || log_m < log_n) return -1;
+    if (threads < 1) threads = 1;
+    const f4_ctx *fr = fr_of(curve);
+    const size_t n = (size_t)1 << log_n, m = (size_t)1 << log_m, ratio = m / n;
+    uint64_t wm[4], g[4], one[4], nn[4], alpha2[4];
+    domain_gen(curve, log_m, wm);
+    f4_from_u64(fr, g, curve == 0 ? 5 : 7);
+    memcpy(one, fr->r1, 32);
+    f4_from_u64(fr, nn, (uint64_t)n);
+    f4_sqr(fr, alpha2, alpha);
+    /* z_h_inv[i] = 1 / ((g w^i)^n - 1), i < ratio   (prover.rs:509-516) */
+    uint64_t *zh = (uint64_t *)malloc(32 * ratio);
+    for (size_t i = 0; i < ratio; i++) {
+        uint64_t x[4], e[1] = {i};
+        f4_pow(fr, x, wm, e, 1);
+        f4_mul(fr, x, x, g);
+        e[0] = n;
+        f4_pow(fr, x, x, e, 1);
+        f4_sub(fr, x, x, one);
+        f4_inv(fr, zh + 4 * i, x);
+    }
+#pragma omp parallel for num_threads(threads) schedule(static)
+    for (size_t i = 0; i < m; i++) {
+        uint64_t x[4], e[1] = {i}, t[4], u[4], acc[4], w[5][4];
+        f4_pow(fr, x, wm, e, 1);
+        f4_mul(fr, x, x, g); /* eval_point */
+        for (int j = 0; j < 5; j++) memcpy(w[j], wires + 4 * (j * m + i), 32);
+#define SEL(j) (sel + 4 * ((size_t)(j) * m + i))
+        /* gate part :665-699 */
+        f4_add(fr, acc, SEL(11), pi + 4 * i); /* q_c + pi */
+        for (int j = 0; j < 4; j++) {
+            f4_mul(fr, t, SEL(j), w[j]);
+            f4_add(fr, acc, acc, t);
+        }
+        f4_mul(fr, t, SEL(4), w[0]);
+        f4_mul(fr, t, t, w[1]);
+        f4_add(fr, acc, acc, t);
+        f4_mul(fr, t, SEL(5), w[2]);
+        f4_mul(fr, t, t, w[3]);
+        f4_add(fr, acc, acc, t);
+        f4_mul(fr, t, SEL(12), w[0]);
+        for (int j = 1; j < 5; j++) f4_mul(fr, t, t, w[j]);
+        f4_add(fr, acc, acc, t);
+        for (int j = 0; j < 4; j++) {
+            f4_sqr(fr, u, w[j]);
+            f4_sqr(fr, u, u);
+            f4_mul(fr, u, u, w[j]);
+            f4_mul(fr, t, SEL(6 + j), u);
+            f4_add(fr, acc, acc, t);
+        }
+        f4_mul(fr, t, SEL(10), w[4]);
+        f4_sub(fr, acc, acc, t);
+#undef SEL
+        /* copy-constraint part :709-752 */
+        const uint64_t *zx = zperm + 4 * i, *zxw = zperm + 4 * ((i + ratio) % m);
+        uint64_t r1[4], r1b[4];
+        memcpy(r1, zx, 32);
+        for (int j = 0; j < 5; j++) {
+            f4_mul(fr, t, k + 4 * j, x);
+            f4_mul(fr, t, t, beta);
+            f4_add(fr, t, t, w[j]);
+            f4_add(fr, t, t, gamma);
+            f4_mul(fr, r1, r1, t);
+        }
+        f4_mul(fr, r1, r1, alpha);
+        memcpy(r1b, zxw, 32);
+        for (int j = 0; j < 5; j++) {
+            f4_mul(fr, t, sig + 4 * (j * m + i), beta);
+            f4_add(fr, t, t, w[j]);
+            f4_add(fr, t, t, gamma);
+            f4_mul(fr, r1b, r1b, t);
+        }
+        f4_mul(fr, r1b, r1b, alpha);
+        f4_sub(fr, r1, r1, r1b);
+        uint64_t r2[4], den[4];
+        f4_sub(fr, r2, zx, one);
+        f4_mul(fr, r2, r2, alpha2);
+        f4_sub(fr, den, x, one);
+        f4_mul(fr, den, den, nn);
+        f4_inv(fr, den, den);
+        f4_mul(fr, r2, r2, den);
+        /* combine :636-641, :644-655 */
+        f4_add(fr, acc, acc, r1);
+        f4_mul(fr, acc, acc, zh + 4 * (i % ratio));
+        f4_add(fr, acc, acc, r2);
+        f4_mul(fr, acc, acc, alpha_base);
+        f4_add(fr, out + 4 * i, out + 4 * i, acc);
+    }
+    free(zh);
+    return 0;
+}

@@ -381,3 +381,43 @@ class SplitMix64:
             v &= (1 << bits) - 1
             if v < f.p:
                 return v
+
+
+# ----------------------------------------------------------------------------------
+# TurboPlonk quotient evaluations, restating
+# plonk/src/proof_system/prover.rs:587-655 (+ :665-699 gate part, :709-752 copy constraints)
+# ----------------------------------------------------------------------------------
+
+
+def quotient_evals_turbo(cv: Curve, log_n: int, log_m: int, sel, sig, wires, zperm, pi, k, alpha, beta, gamma,
+                         alpha_base=1):
+    """sel: 13 lists, sig/wires: 5 lists, zperm/pi: lists -- all coset evaluations (offset
+    Fr::GENERATOR) over the size-2^log_m domain, as integers.  Returns alpha_base * t_i."""
+    r = cv.fr.p
+    n, m = 1 << log_n, 1 << log_m
+    ratio = m // n
+    wm = domain_root(cv, log_m)
+    g = cv.fr_generator
+    zh_inv = [pow((pow(g * pow(wm, i, r) % r, n, r) - 1) % r, -1, r) for i in range(ratio)]
+    out = []
+    for i in range(m):
+        x = g * pow(wm, i, r) % r
+        w = [wires[j][i] for j in range(5)]
+        q_lc = [sel[j][i] for j in range(4)]
+        q_mul = [sel[4][i], sel[5][i]]
+        q_hash = [sel[6 + j][i] for j in range(4)]
+        q_o, q_c, q_ecc = sel[10][i], sel[11][i], sel[12][i]
+        t_circ = (q_c + pi[i] + sum(q_lc[j] * w[j] for j in range(4)) + q_mul[0] * w[0] * w[1]
+                  + q_mul[1] * w[2] * w[3] + q_ecc * w[0] * w[1] * w[2] * w[3] * w[4]
+                  + sum(q_hash[j] * pow(w[j], 5, r) for j in range(4)) - q_o * w[4]) % r
+        a = zperm[i]
+        for j in range(5):
+            a = a * (w[j] + k[j] * x * beta + gamma) % r
+        b = zperm[(i + ratio) % m]
+        for j in range(5):
+            b = b * (w[j] + sig[j][i] * beta + gamma) % r
+        t_perm_1 = alpha * (a - b) % r
+        t_perm_2 = alpha * alpha * (zperm[i] - 1) % r * pow(n * (x - 1) % r, -1, r) % r
+        t = ((t_circ + t_perm_1) * zh_inv[i % ratio] + t_perm_2) % r
+        out.append(alpha_base * t % r)
+    return out
