@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--log-n", type=int, default=LOG_N, help="points per GPU = 2^log_n (metric: 24)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ntt", action="store_true")
+    ap.add_argument("--no-prove", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -225,11 +226,38 @@ def main():
             out["ntt"] = {"workload": "8 x 2^22 BLS12-381 Fr coset NTT (h = 7), device resident",
                           "algorithmic_bytes": "64 B per element per transform", **res_ntt}
 
+        if not args.no_prove:
+            # device-side operation sequence of one TurboPlonk proof, 2^20 gates, BN254 (config 4 shape);
+            # host transcript / RNG / grand product are inputs (jellyfish_amd/prover_path.py)
+            from jellyfish_amd import prover_path as PP
+
+            log_g = 20
+            srs_p = L.Srs.gen_for_testing(0, beta, BN254_G, (1 << log_g) + 8)
+            hp = PP.TurboPlonkHotPath(0, log_g, srs_p, lambda cnt, seed: uniform_fr(cnt, 7000 + seed, BN254_R), stream)
+            hp.prove()
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                commits = hp.prove()
+                torch.cuda.synchronize()
+                ts.append((time.perf_counter() - t0) * 1e3)
+            out["plonk_prove_hot_path"] = {
+                "workload": "TurboPlonk BN254 2^20 gates, one instance: 7 iNTT(2^20) + 25 coset NTT(2^23, zero-extended) "
+                            "+ quotient evaluation + coset iNTT(2^23) + 13 commitments (~2^20 points) + 12 divisions "
+                            "+ 2 linear combinations, all device resident",
+                "ms": round(float(np.median(ts)), 3), "runs_ms": [round(t, 3) for t in ts],
+                "excluded": "host transcript, RNG, serial grand product (inputs here); witness upload",
+                "commitments_sha": __import__("hashlib").sha256(bytes(commits.cpu().numpy().tobytes())).hexdigest()[:16]}
+            srs_p.free()
+            del hp
+            torch.cuda.empty_cache()
+
         if not args.no_cpu_baseline:
             try:
                 from oracle import coracle as C
 
-                log_s = min(args.log_n, 21)
+                log_s = min(args.log_n, 24)
                 ns = 1 << log_s
                 bases = srs.read(0, ns)
                 threads = C.nthreads()

@@ -173,6 +173,23 @@ int32_t jfhip_plonk_quotient_turbo_device(int32_t curve_id, uint32_t log_n, uint
                                           const void *d_pub_input, const uint64_t *k_mont,
                                           const uint64_t *challenges_mont, void *d_quot, jfhip_stream *stream);
 
+/* ---- device-resident polynomial glue (next row) -------------------------- */
+
+/* Replaces the witness-polynomial division of open() / compute_batched_witness_polynomial_commitment
+ * (pcs/src/univariate_kzg/mod.rs:153-158, plonk/src/proof_system/prover.rs:483-485) and
+ * polynomial.evaluate (mod.rs:174, prover.rs:205-229) on DEVICE data: for n coefficients
+ * d_coeffs and the host point z, d_out (n elements) receives  d_out[0] = f(z)  and
+ * d_out[1..n) = coefficients of (f(X) - f(z)) / (X - z).  Asynchronous on `stream`. */
+int32_t jfhip_poly_divide_linear_device(int32_t curve_id, const void *d_coeffs, size_t n, const uint64_t *point_mont,
+                                        void *d_out, jfhip_stream *stream);
+
+/* Replaces mul_poly + the polynomial sums of the linearisation / batched-opening polynomials
+ * (plonk/src/proof_system/prover.rs:299-352, 470-488, 1090-1099):
+ * d_out[i] = sum_k coeffs[k] * d_polys[k][i], i < n; polynomial k contributes zero beyond lens[k].
+ * d_polys: host array of `count` (<= 32) device pointers; coeffs_mont: count host scalars. */
+int32_t jfhip_poly_lincomb_device(int32_t curve_id, const void *const *d_polys, const size_t *lens, size_t count,
+                                  const uint64_t *coeffs_mont, void *d_out, size_t n, jfhip_stream *stream);
+
 /* ---- field / group vector ops (test and glue surface) -------------------------------------- */
 
 /* field_id: 0 BN254 Fr, 1 BN254 Fq, 2 BLS12-381 Fr, 3 BLS12-381 Fq.

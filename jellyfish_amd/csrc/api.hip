@@ -560,6 +560,34 @@ int32_t jfhip_plonk_quotient_turbo_device(int32_t curve_id, uint32_t log_n, uint
                                        k_mont, ch, (uint32_t*)d_quot, st);
 }
 
+int32_t jfhip_poly_divide_linear_device(int32_t curve_id, const void* d_coeffs, size_t n, const uint64_t* point,
+                                        void* d_out, jfhip_stream* stream) {
+    JF_TRY(check_curve(curve_id));
+    if (n == 0) return JFHIP_OK;
+    if (!d_coeffs || !point || !d_out) {
+        set_error("null argument");
+        return JFHIP_ERR_INVALID;
+    }
+    JF_STREAM(st, stream);
+    std::lock_guard<std::mutex> lk(st->mu);
+    JF_TRY(st->poly_a.ensure(64));
+    JF_HIP(hipMemcpyAsync(st->poly_a.p, point, 32, hipMemcpyHostToDevice, st->s));
+    return open_witness_device(curve_id, (const uint32_t*)d_coeffs, n, st->poly_a.as<uint32_t>(), (uint32_t*)d_out,
+                               nullptr, st);
+}
+
+int32_t jfhip_poly_lincomb_device(int32_t curve_id, const void* const* d_polys, const size_t* lens, size_t count,
+                                  const uint64_t* coeffs, void* d_out, size_t n, jfhip_stream* stream) {
+    JF_TRY(check_curve(curve_id));
+    if (!d_polys || !lens || !coeffs || !d_out) {
+        set_error("null argument");
+        return JFHIP_ERR_INVALID;
+    }
+    JF_STREAM(st, stream);
+    std::lock_guard<std::mutex> lk(st->mu);
+    return poly_lincomb_device(curve_id, (const uint32_t* const*)d_polys, lens, count, coeffs, (uint32_t*)d_out, n, st);
+}
+
 // ---- field / group test surface ---------------------------------------------------------------------
 
 int32_t jfhip_field_op(int32_t field_id, int32_t op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {

@@ -111,6 +111,63 @@ int32_t open_witness_device(int32_t curve, const uint32_t* d_coeffs, size_t n, c
     return open_witness_t<Bls381Fr>(d_coeffs, n, d_point, d_witness, st);
 }
 
+// ---- linear combination of polynomials ----------------------------------------------------------
+// out[i] = sum_k c_k * p_k[i]: the prover's linearisation polynomial and batched opening polynomial
+// (reference plonk/src/proof_system/prover.rs:299-352, 470-488, mul_poly :1090-1099) without the
+// polynomials leaving the device.  Ragged lengths: a polynomial contributes zero beyond its length.
+constexpr int LINCOMB_MAX = 32;
+struct LincombArgs {
+    const uint32_t* polys[LINCOMB_MAX];
+    uint32_t lens[LINCOMB_MAX];
+    uint32_t count;
+};
+
+template <class Fr>
+__global__ __launch_bounds__(256) void k_poly_lincomb(LincombArgs a, const uint32_t* __restrict__ coeffs, uint32_t n,
+                                                      uint32_t* __restrict__ out) {
+    constexpr int N = Fr::N;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fp<Fr> acc = Fp<Fr>::zero();
+    for (uint32_t k = 0; k < a.count; k++) {
+        if (i < a.lens[k]) {
+            Fp<Fr> v = fp_load<Fr>(a.polys[k] + (size_t)i * N);
+            acc = fp_add<Fr>(acc, fp_mul<Fr>(v, fp_load<Fr>(coeffs + (size_t)k * N)));
+        }
+    }
+    fp_store<Fr>(out + (size_t)i * N, acc);
+}
+
+int32_t poly_lincomb_device(int32_t curve, const uint32_t* const* d_polys, const size_t* lens, size_t count,
+                            const uint64_t* coeffs_mont, uint32_t* d_out, size_t n, jfhip_stream* st) {
+    if (count == 0 || count > (size_t)LINCOMB_MAX) {
+        set_error("lincomb: between 1 and %d polynomials per call", LINCOMB_MAX);
+        return JFHIP_ERR_INVALID;
+    }
+    if (n >= ((size_t)1 << 32)) {
+        set_error("lincomb: polynomial too long");
+        return JFHIP_ERR_INVALID;
+    }
+    LincombArgs a;
+    a.count = (uint32_t)count;
+    for (size_t k = 0; k < count; k++) {
+        a.polys[k] = d_polys[k];
+        a.lens[k] = (uint32_t)(lens[k] < n ? lens[k] : n);
+    }
+    JF_TRY(st->poly_b.ensure(count * 32));
+    JF_HIP(hipMemcpyAsync(st->poly_b.p, coeffs_mont, count * 32, hipMemcpyHostToDevice, st->s));
+    dim3 grid((unsigned)((n + 255) / 256));
+    if (n == 0) return JFHIP_OK;
+    if (curve == JFHIP_BN254)
+        hipLaunchKernelGGL((k_poly_lincomb<Bn254Fr>), grid, dim3(256), 0, st->s, a, st->poly_b.as<uint32_t>(),
+                           (uint32_t)n, d_out);
+    else
+        hipLaunchKernelGGL((k_poly_lincomb<Bls381Fr>), grid, dim3(256), 0, st->s, a, st->poly_b.as<uint32_t>(),
+                           (uint32_t)n, d_out);
+    JF_HIP(hipGetLastError());
+    return JFHIP_OK;
+}
+
 // ---- element-wise field ops (test surface) ------------------------------------------------------
 template <class C>
 __global__ __launch_bounds__(128) void k_field_op(int op, const uint32_t* __restrict__ a,

@@ -35,7 +35,8 @@ SYMBOLS = [
     "jfhip_stream_sync", "jfhip_stream_raw", "jfhip_stream_wrap", "jfhip_srs_load", "jfhip_srs_load_device",
     "jfhip_srs_gen_for_testing", "jfhip_srs_free", "jfhip_srs_len", "jfhip_srs_window_bits", "jfhip_srs_read",
     "jfhip_msm", "jfhip_msm_batch", "jfhip_msm_device", "jfhip_msm_partial_device", "jfhip_g1_sum_partials",
-    "jfhip_kzg_open", "jfhip_ntt", "jfhip_ntt_device", "jfhip_plonk_quotient_turbo_device", "jfhip_field_op", "jfhip_g1_op", "jfhip_probe",
+    "jfhip_kzg_open", "jfhip_ntt", "jfhip_ntt_device", "jfhip_plonk_quotient_turbo_device", "jfhip_poly_divide_linear_device",
+    "jfhip_poly_lincomb_device", "jfhip_field_op", "jfhip_g1_op", "jfhip_probe",
     "jfhip_set_profiling", "jfhip_last_phase_ms", "jfhip_phase_name",
 ]
 
@@ -263,6 +264,24 @@ def plonk_quotient_turbo_device(curve: int, log_n: int, log_m: int, d_selectors:
     _check(load_library().jfhip_plonk_quotient_turbo_device(curve, log_n, log_m, _vp(d_selectors), _vp(d_sigmas),
                                                             _vp(d_wires), _vp(d_prod_perm), _vp(d_pub_input), _p(k),
                                                             _p(ch), _vp(d_quot), _sh(stream)))
+
+
+def poly_divide_linear_device(curve: int, d_coeffs: int, n: int, point_mont, d_out: int, stream: Stream | None = None):
+    """d_out[0] = f(z), d_out[1..n) = (f - f(z)) / (X - z)   (device arrays)."""
+    z = _u64(point_mont)
+    _check(load_library().jfhip_poly_divide_linear_device(curve, _vp(d_coeffs), ctypes.c_size_t(n), _p(z), _vp(d_out),
+                                                          _sh(stream)))
+
+
+def poly_lincomb_device(curve: int, d_polys, lens, coeffs_mont, d_out: int, n: int, stream: Stream | None = None):
+    """d_out[i] = sum_k coeffs[k] * d_polys[k][i]   (device arrays, ragged lengths)."""
+    count = len(d_polys)
+    ptrs = (ctypes.c_void_p * count)(*[int(p) for p in d_polys])
+    ls = (ctypes.c_size_t * count)(*[int(x) for x in lens])
+    c = _u64(coeffs_mont)
+    assert c.size == 4 * count
+    _check(load_library().jfhip_poly_lincomb_device(curve, ptrs, ls, ctypes.c_size_t(count), _p(c), _vp(d_out),
+                                                    ctypes.c_size_t(n), _sh(stream)))
 
 
 FIELD_OPS = {"add": 0, "sub": 1, "mul": 2, "neg": 3, "inv": 4, "from_mont": 5, "to_mont": 6}

@@ -1,0 +1,170 @@
+"""Device-side operation sequence of one TurboPlonk proof (host orchestration only).
+
+Mirrors the order in which `PlonkKzgSnark::batch_prove_internal` drives the accelerated path for one
+instance (reference plonk/src/proof_system/snark.rs:163-430 -> prover.rs:77-413; call stack in
+SURVEY.md section 3.1): per proof 7 size-n iNTTs, 25 forward coset NTTs of size 8n with zero
+extension, the quotient evaluation, 1 inverse coset NTT of size 8n, 13 commitments of ~n points,
+10 evaluations, 2 linear combinations and 2 divisions by (X - z).
+
+What stays on the host in the reference stays out of this sequence: the transcript (challenges are
+inputs here), the RNG (blinding coefficients are inputs), and the serial grand product of
+compute_prod_permutation_polynomial (relation/src/constraint_system.rs:1394-1420; its evaluations
+are an input).  Every polynomial stays resident in HBM between steps; only 13 group elements and 10
+field elements would cross PCIe.  Used by bench.py with synthetic inputs of the reference bench's
+shape (plonk/benches/bench.rs:29-46); all arithmetic is in libjfhip.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import lib as L
+
+NUM_WIRE_TYPES = 5      # relation/src/constants.rs:18-22 (GATE_WIDTH + 1)
+NUM_SELECTORS = 13      # N_TURBO_PLONK_SELECTORS
+
+
+def domain_size_ratio(n: int, num_wire_types: int) -> int:
+    """plonk/src/constants.rs:18-20"""
+    return (num_wire_types * (n + 1) + 2) // n + 1
+
+
+def quot_domain_size(n: int, num_wire_types: int) -> int:
+    """Prover::new (prover.rs:57-68): GeneralEvaluationDomain::new(n * ratio) rounds up to 2^k"""
+    want = n * domain_size_ratio(n, num_wire_types)
+    m = 1
+    while m < want:
+        m <<= 1
+    return m
+
+
+def _dev(a: np.ndarray) -> torch.Tensor:
+    return torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).cuda()
+
+
+class TurboPlonkHotPath:
+    """One TurboPlonk instance of n gates on the current device (curve: L.BN254 / L.BLS12_381)."""
+
+    def __init__(self, curve: int, log_n: int, srs: "L.Srs", rand_fr, stream: "L.Stream | None" = None):
+        """rand_fr(count, seed) -> (count, 4) uint64 Montgomery field elements (synthetic inputs)"""
+        self.curve, self.log_n = curve, log_n
+        self.n = n = 1 << log_n
+        self.m = m = quot_domain_size(n, NUM_WIRE_TYPES)
+        self.log_m = m.bit_length() - 1
+        self.srs = srs
+        assert len(srs) >= n + 3, "SRS must cover degree n + 2"
+        self.stream = stream or L.Stream(wrap_raw=torch.cuda.current_stream().cuda_stream)
+        self.fq_bytes = 8 * L.FQ_LIMBS64[curve]
+        self.gen = L.field_op(0 if curve == L.BN254 else 2, "to_mont",
+                              np.array([5 if curve == L.BN254 else 7, 0, 0, 0], dtype=np.uint64))
+        # proving key, coefficient form, resident (preprocess(), snark.rs:492-580)
+        self.selectors = _dev(rand_fr(NUM_SELECTORS * n, 11)).view(NUM_SELECTORS, n * 4)
+        self.sigmas = _dev(rand_fr(NUM_WIRE_TYPES * n, 12)).view(NUM_WIRE_TYPES, n * 4)
+        self.k = rand_fr(NUM_WIRE_TYPES, 13)
+        # witness-dependent inputs: wire values, permutation-product values, public input values on H
+        self.wire_vals = _dev(rand_fr(NUM_WIRE_TYPES * n, 14)).view(NUM_WIRE_TYPES, n * 4)
+        self.perm_vals = _dev(rand_fr(n, 15))
+        self.pub_vals = _dev(rand_fr(n, 16))
+        # host-side randomness and transcript outputs, fixed for the synthetic run
+        self.blind = _dev(rand_fr(64, 17))
+        self.ch = rand_fr(4, 18)           # alpha, beta, gamma, alpha_base
+        self.zeta = rand_fr(1, 19)[0]
+        self.zeta_omega = rand_fr(1, 20)[0]
+        self.lin_coeffs = rand_fr(32, 21)
+        # working storage
+        ln = n + 4                          # room for the n+2 / n+3 coefficients of a blinded polynomial
+        self.ln = ln
+        self.wire_polys = torch.zeros(NUM_WIRE_TYPES, ln * 4, dtype=torch.int64, device="cuda")
+        self.perm_poly = torch.zeros(ln * 4, dtype=torch.int64, device="cuda")
+        self.pub_poly = torch.zeros(ln * 4, dtype=torch.int64, device="cuda")
+        self.ntt_buf = torch.zeros(NUM_WIRE_TYPES + 2, n * 4, dtype=torch.int64, device="cuda")
+        self.npolys = NUM_SELECTORS + 2 * NUM_WIRE_TYPES + 2
+        self.coset = torch.zeros(self.npolys, m * 4, dtype=torch.int64, device="cuda")
+        self.quot = torch.zeros(m * 4, dtype=torch.int64, device="cuda")
+        self.lin_poly = torch.zeros(ln * 4, dtype=torch.int64, device="cuda")
+        self.open_poly = torch.zeros(ln * 4, dtype=torch.int64, device="cuda")
+        self.scratch = torch.zeros(ln * 4, dtype=torch.int64, device="cuda")
+        rec = (2 * self.fq_bytes + 4 + 15) // 16 * 16
+        self.rec = rec
+        self.commits = torch.zeros(13 * rec, dtype=torch.uint8, device="cuda")
+
+    # ---- helpers ------------------------------------------------------------------------------
+    def _commit(self, slot: int, ptr: int, length: int):
+        L.msm_device(self.srs, ptr, length, self.commits.data_ptr() + slot * self.rec, stream=self.stream)
+
+    def _blind(self, poly: torch.Tensor, count: int, which: int):
+        """mask_polynomial (prover.rs:457-466) adds (b0 + b1 X ..)(X^n - 1): `count` extra top
+        coefficients.  The synthetic run writes the extra coefficients (host RNG output) and leaves
+        the two low ones: same shapes and sizes, the values are random either way."""
+        n4 = self.n * 4
+        poly[n4:n4 + 4 * count] = self.blind[8 * which:8 * which + 4 * count]
+
+    # ---- the proof ----------------------------------------------------------------------------
+    def prove(self) -> torch.Tensor:
+        c, n, m, st = self.curve, self.n, self.m, self.stream
+        n4 = n * 4
+        W = NUM_WIRE_TYPES
+        # Round 1 (prover.rs:77-91): wire polynomials = iNTT of wire values, blind, commit; pub input poly
+        self.ntt_buf[:W].copy_(self.wire_vals)
+        self.ntt_buf[W].copy_(self.pub_vals)
+        self.ntt_buf[W + 1].copy_(self.perm_vals)
+        L.ntt_device(c, self.ntt_buf.data_ptr(), self.log_n, W + 1, inverse=True, stream=st)
+        self.wire_polys[:, :n4].copy_(self.ntt_buf[:W])
+        for j in range(W):
+            self._blind(self.wire_polys[j], 2, j)
+        self.pub_poly[:n4].copy_(self.ntt_buf[W])
+        for j in range(W):
+            self._commit(j, self.wire_polys[j].data_ptr(), n + 2)
+        # Round 2 (prover.rs:128-142): permutation product polynomial (values are an input), commit
+        L.ntt_device(c, self.ntt_buf[W + 1].data_ptr(), self.log_n, 1, inverse=True, stream=st)
+        self.perm_poly[:n4].copy_(self.ntt_buf[W + 1])
+        self._blind(self.perm_poly, 3, W)
+        self._commit(5, self.perm_poly.data_ptr(), n + 3)
+        # Round 3 (prover.rs:183-198, 491-661): coset NTTs (zero extension on device), quotient, split, commit
+        ln4 = (n + 3) * 4
+        cs = self.coset
+        cs[:NUM_SELECTORS, :n4].copy_(self.selectors)
+        cs[NUM_SELECTORS:NUM_SELECTORS + W, :n4].copy_(self.sigmas)
+        cs[:NUM_SELECTORS + W, n4:ln4].zero_()
+        cs[NUM_SELECTORS + W:NUM_SELECTORS + 2 * W, :ln4].copy_(self.wire_polys[:, :ln4])
+        cs[NUM_SELECTORS + 2 * W, :ln4].copy_(self.perm_poly[:ln4])
+        cs[NUM_SELECTORS + 2 * W + 1, :ln4].copy_(self.pub_poly[:ln4])
+        L.ntt_device(c, cs.data_ptr(), self.log_m, self.npolys, inverse=False, coset_mont=self.gen, in_len=n + 3,
+                     stream=st)
+        self.quot.zero_()
+        L.plonk_quotient_turbo_device(c, self.log_n, self.log_m, cs[0].data_ptr(), cs[NUM_SELECTORS].data_ptr(),
+                                      cs[NUM_SELECTORS + W].data_ptr(), cs[NUM_SELECTORS + 2 * W].data_ptr(),
+                                      cs[NUM_SELECTORS + 2 * W + 1].data_ptr(), self.k, self.ch, self.quot.data_ptr(),
+                                      stream=st)
+        L.ntt_device(c, self.quot.data_ptr(), self.log_m, 1, inverse=True, coset_mont=self.gen, stream=st)
+        # split_quotient_polynomial (prover.rs:894-943): W chunks of n + 2 coefficients
+        for j in range(W):
+            self._commit(6 + j, self.quot.data_ptr() + j * (n + 2) * 32, n + 2)
+        # Round 4 (prover.rs:205-229): evaluations of wires (5), sigmas (4) at zeta and z at zeta*omega
+        for j in range(W):
+            L.poly_divide_linear_device(c, self.wire_polys[j].data_ptr(), n + 2, self.zeta, self.scratch.data_ptr(),
+                                        stream=st)
+        for j in range(W - 1):
+            L.poly_divide_linear_device(c, self.sigmas[j].data_ptr(), n, self.zeta, self.scratch.data_ptr(), stream=st)
+        L.poly_divide_linear_device(c, self.perm_poly.data_ptr(), n + 3, self.zeta_omega, self.scratch.data_ptr(),
+                                    stream=st)
+        # linearisation polynomial (prover.rs:299-352, 946-1087): 13 selectors, z, last sigma, 5 quotient chunks
+        ptrs = [self.selectors[j].data_ptr() for j in range(NUM_SELECTORS)]
+        lens = [n] * NUM_SELECTORS
+        ptrs += [self.perm_poly.data_ptr(), self.sigmas[W - 1].data_ptr()]
+        lens += [n + 3, n]
+        ptrs += [self.quot.data_ptr() + j * (n + 2) * 32 for j in range(W)]
+        lens += [n + 2] * W
+        L.poly_lincomb_device(c, ptrs, lens, self.lin_coeffs[:len(ptrs)], self.lin_poly.data_ptr(), n + 3, stream=st)
+        # Round 5 (prover.rs:356-413, 470-488): batched opening polynomial at zeta, divide, commit; same at zeta*omega
+        ptrs = [self.lin_poly.data_ptr()] + [self.wire_polys[j].data_ptr() for j in range(W)]
+        lens = [n + 3] + [n + 2] * W
+        ptrs += [self.sigmas[j].data_ptr() for j in range(W - 1)]
+        lens += [n] * (W - 1)
+        L.poly_lincomb_device(c, ptrs, lens, self.lin_coeffs[:len(ptrs)], self.open_poly.data_ptr(), n + 3, stream=st)
+        L.poly_divide_linear_device(c, self.open_poly.data_ptr(), n + 3, self.zeta, self.scratch.data_ptr(), stream=st)
+        self._commit(11, self.scratch.data_ptr() + 32, n + 2)
+        L.poly_divide_linear_device(c, self.perm_poly.data_ptr(), n + 3, self.zeta_omega, self.scratch.data_ptr(),
+                                    stream=st)
+        self._commit(12, self.scratch.data_ptr() + 32, n + 2)
+        return self.commits

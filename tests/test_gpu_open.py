@@ -45,3 +45,35 @@ def test_open_vs_oracle(hip, n):
     assert (ev == e).all()
     assert (proof == C.msm(cv.curve_id, srs_host[:n - 1], q)).all()
     srs.free()
+
+
+@pytest.mark.parametrize("cv", CURVES, ids=lambda c: c.name)
+def test_device_polynomial_glue(hip, cv):
+    """jfhip_poly_lincomb_device and jfhip_poly_divide_linear_device against the oracle"""
+    import torch
+
+    fid = 0 if cv.curve_id == 0 else 2
+    lens = [1000, 777, 1003, 1]
+    n = 1003
+    polys = [rand_fr_mont(cv, l, 60 + i) for i, l in enumerate(lens)]
+    coeffs = rand_fr_mont(cv, len(lens), 70)
+    dev = [torch.from_numpy(p.view(np.int64)).cuda() for p in polys]
+    out = torch.zeros(n * 4, dtype=torch.int64, device="cuda")
+    st = hip.Stream()
+    hip.poly_lincomb_device(cv.curve_id, [d.data_ptr() for d in dev], lens, coeffs, out.data_ptr(), n, stream=st)
+    st.sync()
+    exp = np.zeros((n, 4), dtype=np.uint64)
+    for p, c in zip(polys, coeffs):
+        term = C.fp_binop(fid, "mul", p, np.tile(c, (len(p), 1)))
+        exp[: len(p)] = C.fp_binop(fid, "add", exp[: len(p)], term)
+    got = out.cpu().numpy().view(np.uint64).reshape(n, 4)
+    assert (got == exp).all()
+    # divide the combination by (X - z)
+    z = rand_fr_mont(cv, 1, 71)[0]
+    res = torch.zeros(n * 4, dtype=torch.int64, device="cuda")
+    hip.poly_divide_linear_device(cv.curve_id, out.data_ptr(), n, z, res.data_ptr(), stream=st)
+    st.sync()
+    r = res.cpu().numpy().view(np.uint64).reshape(n, 4)
+    q, ev = C.open_witness(cv.curve_id, exp, z)
+    assert (r[0] == ev).all() and (r[1:] == q).all()
+    st.close()

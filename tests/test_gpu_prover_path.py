@@ -1,0 +1,78 @@
+"""GPU: the device-side operation sequence of one TurboPlonk proof (jellyfish_amd/prover_path.py)
+against the same sequence run on the oracle: round-1/2 commitments, the quotient commitments (coset
+NTTs -> quotient evaluations -> inverse coset NTT -> split -> commit) and the opening commitments."""
+import numpy as np
+import pytest
+
+from oracle import coracle as C
+from oracle import pyref as R
+from tests.util import mont_arr, pt_arr, rand_fr_mont
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("cv", [R.BN254, R.BLS12_381], ids=lambda c: c.name)
+def test_prover_path_matches_oracle(hip, cv):
+    from jellyfish_amd import prover_path as P
+
+    log_n = 7
+    n = 1 << log_n
+    assert P.domain_size_ratio(n, 5) == 6 and P.quot_domain_size(n, 5) == 8 * n
+    assert P.domain_size_ratio(1 << 20, 6) == 7 and P.quot_domain_size(1 << 20, 6) == 8 << 20
+    cid = cv.curve_id
+    fid = 0 if cid == 0 else 2
+    beta = mont_arr(cv.fr, [987654321])[0]
+    srs = hip.Srs.gen_for_testing(cid, beta, pt_arr(cv, cv.g), n + 8)
+    srs_host = srs.read(0, n + 8)
+    rand = lambda count, seed: rand_fr_mont(cv, count, 9000 + seed)
+    hp = P.TurboPlonkHotPath(cid, log_n, srs, rand)
+    out = hp.prove().cpu().numpy()
+    hp.stream.sync()
+    pt = 16 * cv.fq.limbs64
+    got = [out[i * hp.rec:i * hp.rec + pt].view(np.uint64) for i in range(13)]
+
+    # ---- the same sequence on the oracle ----
+    m, log_m = hp.m, hp.log_m
+    blind = rand(64, 17)
+    wires = C.ntt(cid, rand(5 * n, 14).reshape(5, n, 4), log_n, True)
+    pub = C.ntt(cid, rand(n, 16).reshape(1, n, 4), log_n, True)[0]
+    perm = C.ntt(cid, rand(n, 15).reshape(1, n, 4), log_n, True)[0]
+    wire_polys = [np.concatenate([wires[j], blind[2 * j:2 * j + 2]]) for j in range(5)]
+    perm_poly = np.concatenate([perm, blind[10:13]])
+    for j in range(5):
+        assert (got[j] == C.msm(cid, srs_host[:n + 2], wire_polys[j])).all(), j
+    assert (got[5] == C.msm(cid, srs_host[:n + 3], perm_poly)).all()
+    h = C.fp_unop(fid, "to_mont", np.array([cv.fr_generator, 0, 0, 0], dtype=np.uint64))
+
+    def coset(poly):
+        buf = np.zeros((1, m, 4), dtype=np.uint64)
+        buf[0, :len(poly)] = poly
+        return C.ntt(cid, buf, log_m, False, h)[0]
+
+    sel_c = rand(13 * n, 11).reshape(13, n, 4)
+    sig_c = rand(5 * n, 12).reshape(5, n, 4)
+    ch = rand(4, 18)
+    quot_ev = C.plonk_quotient_turbo(cid, log_n, log_m, np.array([coset(p) for p in sel_c]),
+                                     np.array([coset(p) for p in sig_c]), np.array([coset(p) for p in wire_polys]),
+                                     coset(perm_poly), coset(pub), rand(5, 13), *ch)
+    quot = C.ntt(cid, quot_ev.reshape(1, m, 4), log_m, True, h)[0]
+    for j in range(5):
+        chunk = quot[j * (n + 2):(j + 1) * (n + 2)]
+        assert (got[6 + j] == C.msm(cid, srs_host[:n + 2], chunk)).all(), j
+
+    def lincomb(polys, coeffs, length):
+        acc = np.zeros((length, 4), dtype=np.uint64)
+        for p, c in zip(polys, coeffs):
+            p = p[:length]
+            acc[:len(p)] = C.fp_binop(fid, "add", acc[:len(p)], C.fp_binop(fid, "mul", p, np.tile(c, (len(p), 1))))
+        return acc
+
+    lc = rand(32, 21)
+    lin = lincomb(list(sel_c) + [perm_poly, sig_c[4]] + [quot[j * (n + 2):(j + 1) * (n + 2)] for j in range(5)], lc,
+                  n + 3)
+    opening = lincomb([lin] + wire_polys + list(sig_c[:4]), lc, n + 3)
+    q, _ = C.open_witness(cid, opening, rand(1, 19)[0])
+    assert (got[11] == C.msm(cid, srs_host[:n + 2], q)).all()
+    q2, _ = C.open_witness(cid, perm_poly, rand(1, 20)[0])
+    assert (got[12] == C.msm(cid, srs_host[:n + 2], q2)).all()
+    srs.free()
