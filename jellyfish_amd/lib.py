@@ -46,6 +46,13 @@ def load_library():
     global _LIB
     if _LIB is not None:
         return _LIB
+    # torch ships its own copy of the HIP runtime; if libjfhip.so pulled in /opt/rocm's first, a later
+    # `import torch` would bring up a second runtime in the process and find no devices.  Python users
+    # of this binding hold device memory in torch tensors anyway, so load torch's runtime first.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     path = library_path()
     if not os.path.exists(path):
         raise FileNotFoundError(

@@ -39,7 +39,7 @@ def quot_domain_size(n: int, num_wire_types: int) -> int:
 
 
 def _dev(a: np.ndarray) -> torch.Tensor:
-    return torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).cuda()
+    return torch.from_numpy(np.ascontiguousarray(a).view(np.int64).reshape(-1)).cuda()
 
 
 class TurboPlonkHotPath:
