@@ -40,7 +40,7 @@ struct NttTables {
 struct NttPass {
     const uint32_t* src;
     uint32_t* dst;
-    uint32_t log_n, batch, dbits, log_M, in_len;
+    uint32_t log_n, outer, inner, dbits, log_M, in_len;  // batch = outer (flattened into the grid) x inner (looped)
     int first, final, inverse;
     uint32_t ndig;
     uint32_t dig[4];
@@ -58,20 +58,30 @@ JF_DEV Fp<Fr> two_level(const uint32_t* __restrict__ lo, const uint32_t* __restr
     return x;
 }
 
+// One digit pass.  A workgroup owns one tile position (2^d-point transforms x C adjacent columns) and
+// loops over `inner` polynomials of the batch at that position, so the per-element factors that do
+// not depend on the polynomial -- inter-pass twiddle, coset pre-scale, inverse post-scale -- are
+// built once (two-level table: 2 loads + 1 multiply) and reused from registers: one multiply per
+// element and polynomial instead of two.
+// Zero extension (first pass, in_len < n): only rows jp < 2^rb of the tile are non-zero; after the
+// first s0 = d - rb butterfly layers every group of 2^s0 LDS rows would hold copies of one input
+// (u + 0*w), so those layers are replaced by replicating the scaled input at load time.
 template <class Fr>
 __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPass P) {
     constexpr int N = Fr::N;
+    constexpr int PER = NTT_TILE / NTT_THREADS;  // 8 elements per lane
     __shared__ uint32_t lds[NTT_TILE * N + 128 * N];
     uint32_t* tws = lds + NTT_TILE * N;
     const uint32_t tid = threadIdx.x;
     const uint32_t d = P.dbits;
     const uint32_t logC = NTT_TILE_LOG - d;
     const uint32_t C = 1u << logC;
-    const uint64_t ncols = (uint64_t)P.batch << (P.log_n - d);
+    const uint64_t ncols = (uint64_t)P.outer << (P.log_n - d);
     const uint64_t g0 = (uint64_t)blockIdx.x << logC;
-    const uint32_t log_S = P.log_M - d;                 // stride of this digit inside its row
-    const uint32_t log_rows = P.log_n - P.log_M;        // rows of length M per polynomial
+    const uint32_t log_S = P.log_M - d;           // stride of this digit inside its row
+    const uint32_t log_rows = P.log_n - P.log_M;  // rows of length M per polynomial
     const uint64_t n = 1ull << P.log_n;
+    const size_t poly_stride = (size_t)n * N;
 
     if (tid < 128) {
         Fp<Fr> w = fp_load<Fr>(P.t.tw_small + tid * N);
@@ -107,91 +117,154 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPass P) {
         outbase = k1 + (rev << R1bits);
     };
 
-    // ---- load (bit-reversed along the transform axis) -----------------------------------
-#pragma unroll 2
-    for (int it = 0; it < NTT_TILE / NTT_THREADS; it++) {
+    // ---- zero-extension plan: rows jp < 2^rb carry data, s0 layers are replaced by replication ----
+    uint32_t rb = d;
+    if (P.first && P.in_len < n) {
+        // first pass: idx = (jp << log_S) + jrest with jrest >= jrest0 = first column of the tile
+        uint64_t jrest0 = P.final ? 0 : (g0 & ((1ull << log_S) - 1));
+        uint64_t nz = (P.in_len > jrest0) ? (((uint64_t)P.in_len - 1 - jrest0) >> log_S) + 1 : 1;
+        rb = 0;
+        while ((1ull << rb) < nz) rb++;
+        if (rb > d) rb = d;
+    }
+    const uint32_t s0 = d - rb;
+    const uint32_t n_src = C << rb;  // distinct source elements of the tile
+
+    // ---- per-lane descriptors, independent of the polynomial -----------------------------------
+    uint32_t ld_off[PER];   // element offset of the source (relative to the polynomial group)
+    uint32_t ld_slot[PER];  // first LDS row << logC | col
+    bool ld_ok[PER], ld_scale[PER];
+    Fp<Fr> cf[PER];
+    uint32_t st_off[PER];
+    bool st_ok[PER], st_mul[PER];
+    Fp<Fr> tw[PER];
+#pragma unroll
+    for (int it = 0; it < PER; it++) {
         uint32_t e = it * NTT_THREADS + tid;
-        uint32_t col = e & (C - 1), jp = e >> logC;
-        uint64_t g = g0 + col;
-        Fp<Fr> x = Fp<Fr>::zero();
-        if (g < ncols) {
-            uint32_t poly;
-            uint64_t idx;
-            if (!P.final || P.first) {
-                // (a single-pass transform is both first and final: plain row addressing)
-                uint64_t base;
-                uint32_t jrest;
-                if (P.final) {
-                    poly = (uint32_t)g;
-                    base = 0;
-                } else col_base(g, poly, base, jrest);
-                idx = base + ((uint64_t)jp << log_S);
-            } else {
-                uint64_t row, ob;
-                final_col(g, poly, row, ob);
-                idx = (row << d) + jp;
-            }
-            if (!P.first || idx < P.in_len) {
-                x = fp_load<Fr>(P.src + ((size_t)poly * n + idx) * N);
-                if (P.first && !P.inverse && P.t.scale_mode == 2 && idx)
-                    x = fp_mul<Fr>(x, two_level<Fr>(P.t.cl, P.t.ch, P.t.a, idx));
+        ld_ok[it] = false;
+        ld_scale[it] = false;
+        ld_off[it] = 0;
+        ld_slot[it] = 0;
+        if (e < n_src) {
+            uint32_t col = e & (C - 1), jp = e >> logC;
+            uint64_t g = g0 + col;
+            ld_slot[it] = ((bitrev_n(jp, rb) << s0) << logC) | col;
+            if (g < ncols) {
+                uint32_t poly;
+                uint64_t idx;
+                if (!P.final || P.first) {
+                    uint64_t base;
+                    uint32_t jrest;
+                    if (P.final) {
+                        poly = (uint32_t)g;
+                        base = 0;
+                    } else col_base(g, poly, base, jrest);
+                    idx = base + ((uint64_t)jp << log_S);
+                } else {
+                    uint64_t row, ob;
+                    final_col(g, poly, row, ob);
+                    idx = (row << d) + jp;
+                }
+                if (!P.first || idx < P.in_len) {
+                    ld_ok[it] = true;
+                    ld_off[it] = (uint32_t)((uint64_t)poly * n + idx);
+                    if (P.first && !P.inverse && P.t.scale_mode == 2 && idx) {
+                        ld_scale[it] = true;
+                        cf[it] = two_level<Fr>(P.t.cl, P.t.ch, P.t.a, idx);
+                    }
+                }
             }
         }
-        fp_store<Fr>(lds + (((size_t)bitrev_n(jp, d) << logC) + col) * N, x);
-    }
-    __syncthreads();
-
-    // ---- d butterfly layers (decimation in time) --------------------------------------------
-    for (uint32_t s = 1; s <= d; s++) {
-        const uint32_t log_half = s - 1, half = 1u << log_half;
-#pragma unroll 2
-        for (int it = 0; it < NTT_TILE / 2 / NTT_THREADS; it++) {
-            uint32_t bf = it * NTT_THREADS + tid;
-            uint32_t col = bf & (C - 1), q = bf >> logC;
-            uint32_t j = q & (half - 1), grp = q >> log_half;
-            uint32_t i0 = (grp << s) + j, i1 = i0 + half;
-            uint32_t* p0 = lds + (((size_t)i0 << logC) + col) * N;
-            uint32_t* p1 = lds + (((size_t)i1 << logC) + col) * N;
-            Fp<Fr> u = fp_load<Fr>(p0), v = fp_load<Fr>(p1);
-            if (j) v = fp_mul<Fr>(v, fp_load<Fr>(tws + (size_t)(j << (7 - log_half)) * N));
-            fp_store<Fr>(p0, fp_add<Fr>(u, v));
-            fp_store<Fr>(p1, fp_sub<Fr>(u, v));
-        }
-        __syncthreads();
-    }
-
-    // ---- store ----------------------------------------------------------------------------------
-#pragma unroll 2
-    for (int it = 0; it < NTT_TILE / NTT_THREADS; it++) {
-        uint32_t e = it * NTT_THREADS + tid;
+        // store side
         uint32_t col = e & (C - 1), k = e >> logC;
         uint64_t g = g0 + col;
-        if (g >= ncols) continue;
-        Fp<Fr> x = fp_load<Fr>(lds + (((size_t)k << logC) + col) * N);
-        uint32_t poly;
-        uint64_t pos;
-        if (!P.final) {
-            uint64_t base;
-            uint32_t jrest;
-            col_base(g, poly, base, jrest);
-            pos = base + ((uint64_t)k << log_S);
-            uint64_t E = ((uint64_t)k * jrest) << log_rows;  // exponent of w_n
-            if (E) x = fp_mul<Fr>(x, two_level<Fr>(P.t.tl, P.t.th, P.t.a, E));
-        } else {
-            if (P.ndig == 1) {
-                poly = (uint32_t)g;
-                pos = k;
+        st_ok[it] = g < ncols;
+        st_mul[it] = false;
+        st_off[it] = 0;
+        if (st_ok[it]) {
+            uint32_t poly;
+            uint64_t pos;
+            if (!P.final) {
+                uint64_t base;
+                uint32_t jrest;
+                col_base(g, poly, base, jrest);
+                pos = base + ((uint64_t)k << log_S);
+                uint64_t E = ((uint64_t)k * jrest) << log_rows;  // exponent of w_n
+                if (E) {
+                    st_mul[it] = true;
+                    tw[it] = two_level<Fr>(P.t.tl, P.t.th, P.t.a, E);
+                }
             } else {
-                uint64_t row, ob;
-                final_col(g, poly, row, ob);
-                pos = ob + ((uint64_t)k << log_NR);
+                if (P.ndig == 1) {
+                    poly = (uint32_t)g;
+                    pos = k;
+                } else {
+                    uint64_t row, ob;
+                    final_col(g, poly, row, ob);
+                    pos = ob + ((uint64_t)k << log_NR);
+                }
+                if (P.inverse && P.t.scale_mode == 1) {
+                    st_mul[it] = true;
+                    tw[it] = fp_load<Fr>(P.t.params + 2 * N);
+                } else if (P.inverse && P.t.scale_mode == 2) {
+                    st_mul[it] = true;
+                    tw[it] = two_level<Fr, true>(P.t.cl, P.t.ch, P.t.a, pos);
+                }
             }
-            if (P.inverse) {
-                if (P.t.scale_mode == 1) x = fp_mul<Fr>(x, fp_load<Fr>(P.t.params + 2 * N));
-                else if (P.t.scale_mode == 2) x = fp_mul<Fr>(x, two_level<Fr, true>(P.t.cl, P.t.ch, P.t.a, pos));
+            st_off[it] = (uint32_t)((uint64_t)poly * n + pos);
+        }
+    }
+
+    for (uint32_t b = 0; b < P.inner; b++) {
+        const uint32_t* src = P.src + (size_t)b * poly_stride;
+        uint32_t* dst = P.dst + (size_t)b * poly_stride;
+        // ---- load (bit-reversed along the transform axis, replicated over skipped layers) ------
+#pragma unroll
+        for (int it = 0; it < PER; it++) {
+            uint32_t e = it * NTT_THREADS + tid;
+            if (e < n_src) {
+                Fp<Fr> x = Fp<Fr>::zero();
+                if (ld_ok[it]) {
+                    x = fp_load<Fr>(src + (size_t)ld_off[it] * N);
+                    if (ld_scale[it]) x = fp_mul<Fr>(x, cf[it]);
+                }
+                uint32_t col = ld_slot[it] & (C - 1), r0 = ld_slot[it] >> logC;
+                for (uint32_t t = 0; t < (1u << s0); t++) fp_store<Fr>(lds + (((size_t)(r0 + t) << logC) + col) * N, x);
             }
         }
-        fp_store<Fr>(P.dst + ((size_t)poly * n + pos) * N, x);
+        __syncthreads();
+
+        // ---- butterfly layers s0+1 .. d (decimation in time) ------------------------------------
+        for (uint32_t s = s0 + 1; s <= d; s++) {
+            const uint32_t log_half = s - 1, half = 1u << log_half;
+#pragma unroll 2
+            for (int it = 0; it < NTT_TILE / 2 / NTT_THREADS; it++) {
+                uint32_t bf = it * NTT_THREADS + tid;
+                uint32_t col = bf & (C - 1), q = bf >> logC;
+                uint32_t j = q & (half - 1), grp = q >> log_half;
+                uint32_t i0 = (grp << s) + j, i1 = i0 + half;
+                uint32_t* p0 = lds + (((size_t)i0 << logC) + col) * N;
+                uint32_t* p1 = lds + (((size_t)i1 << logC) + col) * N;
+                Fp<Fr> u = fp_load<Fr>(p0), v = fp_load<Fr>(p1);
+                if (j) v = fp_mul<Fr>(v, fp_load<Fr>(tws + (size_t)(j << (7 - log_half)) * N));
+                fp_store<Fr>(p0, fp_add<Fr>(u, v));
+                fp_store<Fr>(p1, fp_sub<Fr>(u, v));
+            }
+            __syncthreads();
+        }
+
+        // ---- store ------------------------------------------------------------------------------
+#pragma unroll
+        for (int it = 0; it < PER; it++) {
+            uint32_t e = it * NTT_THREADS + tid;
+            uint32_t col = e & (C - 1), k = e >> logC;
+            if (st_ok[it]) {
+                Fp<Fr> x = fp_load<Fr>(lds + (((size_t)k << logC) + col) * N);
+                if (st_mul[it]) x = fp_mul<Fr>(x, tw[it]);
+                fp_store<Fr>(dst + (size_t)st_off[it] * N, x);
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -389,14 +462,17 @@ static int32_t ntt_device_t(int32_t curve, uint32_t* d_data, uint32_t log_n, siz
         P.src = (p == 0) ? d_data : tmp;
         P.dst = (ndig == 1 || P.final) ? d_data : tmp;
         P.log_n = log_n;
-        P.batch = (uint32_t)batch;
+        // tiles must not straddle polynomials to loop over the batch inside a workgroup
+        const bool loop_inside = (log_n - dig[p]) >= (NTT_TILE_LOG - dig[p]);
+        P.outer = loop_inside ? 1u : (uint32_t)batch;
+        P.inner = loop_inside ? (uint32_t)batch : 1u;
         P.dbits = dig[p];
         P.log_M = log_M;
         P.in_len = (uint32_t)in_len;
         P.ndig = ndig;
         for (int q = 0; q < 4; q++) P.dig[q] = dig[q];
         P.t = tabs;
-        uint64_t ncols = (uint64_t)batch << (log_n - dig[p]);
+        uint64_t ncols = (uint64_t)P.outer << (log_n - dig[p]);
         uint32_t logC = NTT_TILE_LOG - dig[p];
         uint64_t blocks = (ncols + (1ull << logC) - 1) >> logC;
         hipLaunchKernelGGL((k_ntt_pass<Fr>), dim3((unsigned)blocks), dim3(NTT_THREADS), 0, st->s, P);
