@@ -112,6 +112,13 @@ int32_t jfhip_msm(const jfhip_srs *srs, size_t offset, const uint64_t *scalars_m
 int32_t jfhip_msm_batch(const jfhip_srs *srs, const uint64_t *const *scalars_mont, const size_t *lens, size_t batch,
                         void *out_xy, uint8_t *out_infinity, jfhip_stream *stream);
 
+/* batch_commit on DEVICE scalars (the prover keeps its polynomials in HBM): d_scalars is a HOST array
+ * of `batch` device pointers; d_out receives `batch` records of ceil16(2*fq_bytes + 4) bytes, each a
+ * packed affine point followed by a u32 infinity flag.  Asynchronous on `stream`; independent commits
+ * run on internal auxiliary streams that fork from and join into `stream`. */
+int32_t jfhip_msm_batch_device(const jfhip_srs *srs, const void *const *d_scalars_mont, const size_t *lens,
+                               size_t batch, void *d_out, jfhip_stream *stream);
+
 /* Replaces commit_on_gpu (:900-930, 1001-1040): scalars already in DEVICE memory
  * (n Montgomery Fr elements), asynchronous on `stream`; the result is left on the device as
  * one packed affine point followed by a u32 infinity flag (d_out: 2*fq_bytes + 4 bytes,

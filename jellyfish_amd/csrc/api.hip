@@ -3,6 +3,8 @@
 // poly.hip; nothing here computes field or group operations on the host.
 #include <stdarg.h>
 
+#include <functional>
+
 #include "common.hpp"
 
 namespace jf {
@@ -88,7 +90,24 @@ jfhip_stream* resolve_stream(jfhip_stream* s) {
     return t_default_stream;
 }
 
+static void stream_release(jfhip_stream* s);
+static void lanes_release(jfhip_stream* s) {
+    for (int i = 0; i < jfhip_stream::MAX_LANES - 1; i++) {
+        if (s->lane[i]) {
+            (void)hipStreamSynchronize(s->lane[i]->s);
+            stream_release(s->lane[i]);
+            delete s->lane[i];
+            s->lane[i] = nullptr;
+        }
+        if (s->join_ev[i]) (void)hipEventDestroy(s->join_ev[i]);
+        s->join_ev[i] = nullptr;
+    }
+    if (s->fork_ev) (void)hipEventDestroy(s->fork_ev);
+    s->fork_ev = nullptr;
+}
+
 static void stream_release(jfhip_stream* s) {
+    lanes_release(s);
     DevBuf* bufs[] = {&s->scalars, &s->dig, &s->dig2, &s->midbase, &s->midcnt, &s->midcur, &s->finecnt, &s->finecur, &s->sorted, &s->counts, &s->offs,   &s->cursor, &s->bsum,
                       &s->buckets, &s->partA, &s->partB, &s->red0,   &s->red1,   &s->result, &s->ntt_tmp,
                       &s->ntt_io,  &s->poly_a, &s->poly_b, &s->poly_c, &s->quot_consts};
@@ -394,6 +413,75 @@ int32_t jfhip_g1_sum_partials(int32_t curve_id, const void* d_partials, size_t c
     return g1_sum_to_affine(curve_id, (const uint32_t*)d_partials, count, (uint32_t*)d_out, st);
 }
 
+// Independent MSMs of a batch, fanned out over up to MAX_LANES streams that fork from / join into st->s.
+// `stage` (optional) uploads the scalars of entry b on the lane's stream and returns their device pointer.
+static int32_t msm_batch_locked(const jfhip_srs* srs, const size_t* lens, size_t batch, uint8_t* d_res, size_t rec,
+                                jfhip_stream* st,
+                                const std::function<int32_t(size_t, jfhip_stream*, const void**)>& stage) {
+    size_t maxlen = 0;
+    for (size_t b = 0; b < batch; b++) maxlen = lens[b] > maxlen ? lens[b] : maxlen;
+    // lanes only pay off while the tails are a visible fraction of an MSM; each lane holds a workspace
+    int lanes = 1;
+    if (batch > 1 && maxlen * (size_t)srs->W <= ((size_t)1 << 26)) lanes = batch < 3 ? (int)batch : 3;
+    if (lanes > 1) {
+        if (!st->fork_ev) JF_HIP(hipEventCreateWithFlags(&st->fork_ev, hipEventDisableTiming));
+        for (int i = 0; i < lanes - 1; i++) {
+            if (!st->lane[i]) {
+                jfhip_stream* ls = new jfhip_stream();
+                hipError_t e = hipStreamCreateWithFlags(&ls->s, hipStreamNonBlocking);
+                if (e != hipSuccess) {
+                    delete ls;
+                    return hip_fail(e, "hipStreamCreate(lane)", __FILE__, __LINE__);
+                }
+                ls->owned = true;
+                st->lane[i] = ls;
+            }
+            if (!st->join_ev[i]) JF_HIP(hipEventCreateWithFlags(&st->join_ev[i], hipEventDisableTiming));
+        }
+        JF_HIP(hipEventRecord(st->fork_ev, st->s));
+        for (int i = 0; i < lanes - 1; i++) JF_HIP(hipStreamWaitEvent(st->lane[i]->s, st->fork_ev, 0));
+    }
+    for (size_t b = 0; b < batch; b++) {
+        jfhip_stream* ls = (b % lanes == 0) ? st : st->lane[b % lanes - 1];
+        const void* d_scalars = nullptr;
+        JF_TRY(stage(b, ls, &d_scalars));
+        JF_TRY(msm_device_locked(srs, 0, d_scalars, lens[b], d_res + b * rec, ls));
+    }
+    for (int i = 0; i < lanes - 1; i++) {
+        JF_HIP(hipEventRecord(st->join_ev[i], st->lane[i]->s));
+        JF_HIP(hipStreamWaitEvent(st->s, st->join_ev[i], 0));
+    }
+    return JFHIP_OK;
+}
+
+int32_t jfhip_msm_batch_device(const jfhip_srs* srs, const void* const* d_scalars, const size_t* lens, size_t batch,
+                               void* d_out, jfhip_stream* stream) {
+    if (!srs) {
+        set_error("null SRS handle");
+        return JFHIP_ERR_INVALID;
+    }
+    if (batch == 0) return JFHIP_OK;
+    if (!d_scalars || !lens || !d_out) {
+        set_error("null argument");
+        return JFHIP_ERR_INVALID;
+    }
+    for (size_t b = 0; b < batch; b++) {
+        JF_TRY(check_msm_range(srs, 0, lens[b]));
+        if (lens[b] && !d_scalars[b]) {
+            set_error("null scalar pointer for batch entry %zu", b);
+            return JFHIP_ERR_INVALID;
+        }
+    }
+    JF_STREAM(st, stream);
+    std::lock_guard<std::mutex> lk(st->mu);
+    const size_t rec = (2 * (size_t)fq_bytes(srs->curve) + 4 + 15) & ~(size_t)15;
+    return msm_batch_locked(srs, lens, batch, (uint8_t*)d_out, rec, st,
+                            [&](size_t b, jfhip_stream*, const void** out) -> int32_t {
+                                *out = d_scalars[b];
+                                return JFHIP_OK;
+                            });
+}
+
 int32_t jfhip_msm_batch(const jfhip_srs* srs, const uint64_t* const* scalars, const size_t* lens, size_t batch,
                         void* out_xy, uint8_t* out_inf, jfhip_stream* stream) {
     if (!srs) {
@@ -418,13 +506,18 @@ int32_t jfhip_msm_batch(const jfhip_srs* srs, const uint64_t* const* scalars, co
     std::lock_guard<std::mutex> lk(st->mu);
     const size_t pt = 2 * (size_t)fq_bytes(srs->curve);
     const size_t rec = (pt + 4 + 15) & ~(size_t)15;
-    JF_TRY(st->scalars.ensure((maxlen ? maxlen : 1) * 32));
     JF_TRY(st->ntt_io.ensure(batch * rec));  // result records
     uint8_t* d_res = st->ntt_io.as<uint8_t>();
-    for (size_t b = 0; b < batch; b++) {
-        if (lens[b]) JF_HIP(hipMemcpyAsync(st->scalars.p, scalars[b], lens[b] * 32, hipMemcpyHostToDevice, st->s));
-        JF_TRY(msm_device_locked(srs, 0, st->scalars.p, lens[b], d_res + b * rec, st));
-    }
+    JF_TRY(msm_batch_locked(srs, lens, batch, d_res, rec, st,
+                            [&](size_t b, jfhip_stream* ls, const void** out) -> int32_t {
+                                // each lane stages its scalars in its own buffer, on its own stream
+                                JF_TRY(ls->scalars.ensure((maxlen ? maxlen : 1) * 32));
+                                if (lens[b])
+                                    JF_HIP(hipMemcpyAsync(ls->scalars.p, scalars[b], lens[b] * 32,
+                                                          hipMemcpyHostToDevice, ls->s));
+                                *out = ls->scalars.p;
+                                return JFHIP_OK;
+                            }));
     std::vector<uint8_t> host(batch * rec);
     JF_HIP(hipMemcpyAsync(host.data(), d_res, batch * rec, hipMemcpyDeviceToHost, st->s));
     JF_HIP(hipStreamSynchronize(st->s));

@@ -55,6 +55,11 @@ struct jfhip_stream {
     jf::DevBuf ntt_tmp, ntt_io;
     // open()
     jf::DevBuf poly_a, poly_b, poly_c, quot_consts;
+    // lanes for batched commits: independent MSMs run on auxiliary streams (each with its own workspace)
+    // so the latency-bound reduction tail of one overlaps the bucket accumulation of the next
+    static constexpr int MAX_LANES = 3;
+    jfhip_stream* lane[MAX_LANES - 1] = {};
+    hipEvent_t fork_ev = nullptr, join_ev[MAX_LANES - 1] = {};
     // phase timing
     hipEvent_t ev[jf::MAX_PHASES + 1] = {};
     bool ev_ready = false;

@@ -34,7 +34,7 @@ SYMBOLS = [
     "jfhip_init", "jfhip_last_error", "jfhip_device_count", "jfhip_stream_create", "jfhip_stream_destroy",
     "jfhip_stream_sync", "jfhip_stream_raw", "jfhip_stream_wrap", "jfhip_srs_load", "jfhip_srs_load_device",
     "jfhip_srs_gen_for_testing", "jfhip_srs_free", "jfhip_srs_len", "jfhip_srs_window_bits", "jfhip_srs_read",
-    "jfhip_msm", "jfhip_msm_batch", "jfhip_msm_device", "jfhip_msm_partial_device", "jfhip_g1_sum_partials",
+    "jfhip_msm", "jfhip_msm_batch", "jfhip_msm_batch_device", "jfhip_msm_device", "jfhip_msm_partial_device", "jfhip_g1_sum_partials",
     "jfhip_kzg_open", "jfhip_ntt", "jfhip_ntt_device", "jfhip_plonk_quotient_turbo_device", "jfhip_poly_divide_linear_device",
     "jfhip_poly_lincomb_device", "jfhip_field_op", "jfhip_g1_op", "jfhip_probe",
     "jfhip_set_profiling", "jfhip_last_phase_ms", "jfhip_phase_name",
@@ -211,6 +211,14 @@ def msm_batch(srs: Srs, polys, stream: Stream | None = None):
     lens = (ctypes.c_size_t * max(batch, 1))(*[a.size // 4 for a in arrs])
     _check(load_library().jfhip_msm_batch(srs.h, ptrs, lens, ctypes.c_size_t(batch), _p(out), _p(inf), _sh(stream)))
     return out, inf.astype(bool)
+
+
+def msm_batch_device(srs: Srs, d_scalars, lens, d_out: int, stream: Stream | None = None):
+    """batch of commits on device scalars; d_out: len(lens) records of ceil16(2*fq_bytes + 4) bytes"""
+    batch = len(lens)
+    ptrs = (ctypes.c_void_p * max(batch, 1))(*[int(p) for p in d_scalars])
+    ls = (ctypes.c_size_t * max(batch, 1))(*[int(x) for x in lens])
+    _check(load_library().jfhip_msm_batch_device(srs.h, ptrs, ls, ctypes.c_size_t(batch), _vp(d_out), _sh(stream)))
 
 
 def msm_device(srs: Srs, d_scalars: int, n: int, d_out: int, offset: int = 0, stream: Stream | None = None):

@@ -113,8 +113,8 @@ class TurboPlonkHotPath:
         for j in range(W):
             self._blind(self.wire_polys[j], 2, j)
         self.pub_poly[:n4].copy_(self.ntt_buf[W])
-        for j in range(W):
-            self._commit(j, self.wire_polys[j].data_ptr(), n + 2)
+        L.msm_batch_device(self.srs, [self.wire_polys[j].data_ptr() for j in range(W)], [n + 2] * W,
+                           self.commits.data_ptr(), stream=st)
         # Round 2 (prover.rs:128-142): permutation product polynomial (values are an input), commit
         L.ntt_device(c, self.ntt_buf[W + 1].data_ptr(), self.log_n, 1, inverse=True, stream=st)
         self.perm_poly[:n4].copy_(self.ntt_buf[W + 1])
@@ -138,8 +138,8 @@ class TurboPlonkHotPath:
                                       stream=st)
         L.ntt_device(c, self.quot.data_ptr(), self.log_m, 1, inverse=True, coset_mont=self.gen, stream=st)
         # split_quotient_polynomial (prover.rs:894-943): W chunks of n + 2 coefficients
-        for j in range(W):
-            self._commit(6 + j, self.quot.data_ptr() + j * (n + 2) * 32, n + 2)
+        L.msm_batch_device(self.srs, [self.quot.data_ptr() + j * (n + 2) * 32 for j in range(W)], [n + 2] * W,
+                           self.commits.data_ptr() + 6 * self.rec, stream=st)
         # Round 4 (prover.rs:205-229): evaluations of wires (5), sigmas (4) at zeta and z at zeta*omega
         for j in range(W):
             L.poly_divide_linear_device(c, self.wire_polys[j].data_ptr(), n + 2, self.zeta, self.scratch.data_ptr(),
