@@ -190,6 +190,12 @@ int32_t jfhip_plonk_quotient_turbo_device(int32_t curve_id, uint32_t log_n, uint
 int32_t jfhip_poly_divide_linear_device(int32_t curve_id, const void *d_coeffs, size_t n, const uint64_t *point_mont,
                                         void *d_out, jfhip_stream *stream);
 
+/* Replaces Prover::compute_evaluations / polynomial.evaluate (plonk/src/proof_system/prover.rs:205-229,
+ * pcs/src/univariate_kzg/mod.rs:174): d_out[k] = d_polys[k](z) for `count` (<= 32) DEVICE polynomials at
+ * one host point; d_out: count field elements on the device.  Asynchronous on `stream`. */
+int32_t jfhip_poly_eval_batch_device(int32_t curve_id, const void *const *d_polys, const size_t *lens, size_t count,
+                                     const uint64_t *point_mont, void *d_out, jfhip_stream *stream);
+
 /* Replaces mul_poly + the polynomial sums of the linearisation / batched-opening polynomials
  * (plonk/src/proof_system/prover.rs:299-352, 470-488, 1090-1099):
  * d_out[i] = sum_k coeffs[k] * d_polys[k][i], i < n; polynomial k contributes zero beyond lens[k].

@@ -669,6 +669,22 @@ int32_t jfhip_poly_divide_linear_device(int32_t curve_id, const void* d_coeffs, 
                                nullptr, st);
 }
 
+int32_t jfhip_poly_eval_batch_device(int32_t curve_id, const void* const* d_polys, const size_t* lens, size_t count,
+                                     const uint64_t* point, void* d_out, jfhip_stream* stream) {
+    JF_TRY(check_curve(curve_id));
+    if (count == 0) return JFHIP_OK;
+    if (!d_polys || !lens || !point || !d_out) {
+        set_error("null argument");
+        return JFHIP_ERR_INVALID;
+    }
+    JF_STREAM(st, stream);
+    std::lock_guard<std::mutex> lk(st->mu);
+    JF_TRY(st->poly_a.ensure(64));
+    JF_HIP(hipMemcpyAsync(st->poly_a.p, point, 32, hipMemcpyHostToDevice, st->s));
+    return poly_eval_batch_device(curve_id, (const uint32_t* const*)d_polys, lens, count, st->poly_a.as<uint32_t>(),
+                                  (uint32_t*)d_out, st);
+}
+
 int32_t jfhip_poly_lincomb_device(int32_t curve_id, const void* const* d_polys, const size_t* lens, size_t count,
                                   const uint64_t* coeffs, void* d_out, size_t n, jfhip_stream* stream) {
     JF_TRY(check_curve(curve_id));

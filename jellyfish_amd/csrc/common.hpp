@@ -111,6 +111,8 @@ int32_t open_witness_device(int32_t curve, const uint32_t* d_coeffs, size_t n, c
                             uint32_t* d_witness, uint32_t* d_eval, jfhip_stream* st);
 int32_t poly_lincomb_device(int32_t curve, const uint32_t* const* d_polys, const size_t* lens, size_t count,
                             const uint64_t* coeffs_mont, uint32_t* d_out, size_t n, jfhip_stream* st);
+int32_t poly_eval_batch_device(int32_t curve, const uint32_t* const* d_polys, const size_t* lens, size_t count,
+                               const uint32_t* d_point, uint32_t* d_out, jfhip_stream* st);
 int32_t field_op_device(int32_t field_id, int32_t op, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t n,
                         hipStream_t s);
 int32_t g1_op_device(int32_t curve, int32_t op, const uint32_t* P, const uint32_t* Q, uint32_t* out, hipStream_t s);

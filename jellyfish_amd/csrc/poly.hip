@@ -111,6 +111,91 @@ int32_t open_witness_device(int32_t curve, const uint32_t* d_coeffs, size_t n, c
     return open_witness_t<Bls381Fr>(d_coeffs, n, d_point, d_witness, st);
 }
 
+// ---- batched evaluation at one point --------------------------------------------------------------
+// f_p(z) for up to 32 polynomials (prover.rs:205-229 evaluates ~10 polynomials at zeta): the chunk
+// reduction of the scan above without the second sweep, all polynomials in one launch per level.
+constexpr int EVAL_MAX = 32;
+struct EvalArgs {
+    const uint32_t* in[EVAL_MAX];
+    uint32_t* out[EVAL_MAX];
+    uint32_t len[EVAL_MAX];
+};
+template <class Fr>
+__global__ __launch_bounds__(128) void k_horner_chunks_batch(EvalArgs a, const uint32_t* __restrict__ mu_p) {
+    constexpr int N = Fr::N;
+    const uint32_t* in = a.in[blockIdx.y];
+    const uint32_t m = a.len[blockIdx.y];
+    uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t lo = (uint64_t)c * HORNER_K;
+    if (lo >= m) return;
+    uint32_t hi = (uint32_t)((lo + HORNER_K < m) ? lo + HORNER_K : m);
+    Fp<Fr> mu = fp_load<Fr>(mu_p);
+    Fp<Fr> acc = Fp<Fr>::zero();
+    for (uint32_t k = hi; k-- > (uint32_t)lo;) acc = fp_add<Fr>(fp_mul<Fr>(acc, mu), fp_load<Fr>(in + (size_t)k * N));
+    fp_store<Fr>(a.out[blockIdx.y] + (size_t)c * N, acc);
+}
+
+template <class Fr>
+static int32_t poly_eval_batch_t(const uint32_t* const* d_polys, const size_t* lens, size_t count,
+                                 const uint32_t* d_point, uint32_t* d_out, jfhip_stream* st) {
+    constexpr int N = Fr::N;
+    size_t maxlen = 0;
+    for (size_t p = 0; p < count; p++) maxlen = lens[p] > maxlen ? lens[p] : maxlen;
+    if (maxlen >= ((size_t)1 << 32)) {
+        set_error("eval: polynomial too long");
+        return JFHIP_ERR_INVALID;
+    }
+    uint32_t levels = 1;
+    for (size_t m = maxlen; m > 1; m = (m + HORNER_K - 1) / HORNER_K) levels++;
+    const size_t per_poly = (maxlen + HORNER_K - 1) / HORNER_K + 1;  // level-1 size bounds all later levels
+    JF_TRY(st->poly_b.ensure((2 * per_poly * count + levels + 1) * N * 4));
+    uint32_t* buf0 = st->poly_b.as<uint32_t>();
+    uint32_t* buf1 = buf0 + per_poly * count * N;
+    uint32_t* mus = buf1 + per_poly * count * N;
+    hipLaunchKernelGGL((k_horner_mus<Fr>), dim3(1), dim3(64), 0, st->s, d_point, levels, mus);
+    EvalArgs a;
+    std::vector<size_t> cur(count);
+    for (size_t p = 0; p < count; p++) {
+        a.in[p] = d_polys[p];
+        cur[p] = lens[p];
+    }
+    JF_HIP(hipMemsetAsync(d_out, 0, count * N * 4, st->s));  // empty polynomials evaluate to 0
+    uint32_t level = 0;
+    for (;;) {
+        size_t maxcur = 0;
+        for (size_t p = 0; p < count; p++) maxcur = cur[p] > maxcur ? cur[p] : maxcur;
+        if (maxcur == 0) break;
+        const bool last = maxcur <= HORNER_K;
+        uint32_t* dst = (level & 1) ? buf1 : buf0;
+        for (size_t p = 0; p < count; p++) {
+            a.len[p] = (uint32_t)cur[p];
+            a.out[p] = last ? d_out + p * N : dst + p * per_poly * N;
+        }
+        const size_t chunks = (maxcur + HORNER_K - 1) / HORNER_K;
+        hipLaunchKernelGGL((k_horner_chunks_batch<Fr>), dim3((unsigned)((chunks + 127) / 128), (unsigned)count),
+                           dim3(128), 0, st->s, a, mus + (size_t)level * N);
+        if (last) break;
+        for (size_t p = 0; p < count; p++) {
+            a.in[p] = a.out[p];
+            cur[p] = (cur[p] + HORNER_K - 1) / HORNER_K;
+        }
+        level++;
+    }
+    JF_HIP(hipGetLastError());
+    return JFHIP_OK;
+}
+
+int32_t poly_eval_batch_device(int32_t curve, const uint32_t* const* d_polys, const size_t* lens, size_t count,
+                               const uint32_t* d_point, uint32_t* d_out, jfhip_stream* st) {
+    if (count == 0) return JFHIP_OK;
+    if (count > (size_t)EVAL_MAX) {
+        set_error("eval: at most %d polynomials per call", EVAL_MAX);
+        return JFHIP_ERR_INVALID;
+    }
+    if (curve == JFHIP_BN254) return poly_eval_batch_t<Bn254Fr>(d_polys, lens, count, d_point, d_out, st);
+    return poly_eval_batch_t<Bls381Fr>(d_polys, lens, count, d_point, d_out, st);
+}
+
 // ---- linear combination of polynomials ----------------------------------------------------------
 // out[i] = sum_k c_k * p_k[i]: the prover's linearisation polynomial and batched opening polynomial
 // (reference plonk/src/proof_system/prover.rs:299-352, 470-488, mul_poly :1090-1099) without the

@@ -36,7 +36,7 @@ SYMBOLS = [
     "jfhip_srs_gen_for_testing", "jfhip_srs_free", "jfhip_srs_len", "jfhip_srs_window_bits", "jfhip_srs_read",
     "jfhip_msm", "jfhip_msm_batch", "jfhip_msm_batch_device", "jfhip_msm_device", "jfhip_msm_partial_device", "jfhip_g1_sum_partials",
     "jfhip_kzg_open", "jfhip_ntt", "jfhip_ntt_device", "jfhip_plonk_quotient_turbo_device", "jfhip_poly_divide_linear_device",
-    "jfhip_poly_lincomb_device", "jfhip_field_op", "jfhip_g1_op", "jfhip_probe",
+    "jfhip_poly_lincomb_device", "jfhip_poly_eval_batch_device", "jfhip_field_op", "jfhip_g1_op", "jfhip_probe",
     "jfhip_set_profiling", "jfhip_last_phase_ms", "jfhip_phase_name",
 ]
 
@@ -286,6 +286,16 @@ def poly_divide_linear_device(curve: int, d_coeffs: int, n: int, point_mont, d_o
     z = _u64(point_mont)
     _check(load_library().jfhip_poly_divide_linear_device(curve, _vp(d_coeffs), ctypes.c_size_t(n), _p(z), _vp(d_out),
                                                           _sh(stream)))
+
+
+def poly_eval_batch_device(curve: int, d_polys, lens, point_mont, d_out: int, stream: Stream | None = None):
+    """d_out[k] = d_polys[k](z)   (device arrays; d_out: len(lens) field elements)"""
+    count = len(d_polys)
+    ptrs = (ctypes.c_void_p * count)(*[int(p) for p in d_polys])
+    ls = (ctypes.c_size_t * count)(*[int(x) for x in lens])
+    z = _u64(point_mont)
+    _check(load_library().jfhip_poly_eval_batch_device(curve, ptrs, ls, ctypes.c_size_t(count), _p(z), _vp(d_out),
+                                                       _sh(stream)))
 
 
 def poly_lincomb_device(curve: int, d_polys, lens, coeffs_mont, d_out: int, n: int, stream: Stream | None = None):

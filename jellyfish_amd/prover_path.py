@@ -87,6 +87,7 @@ class TurboPlonkHotPath:
         rec = (2 * self.fq_bytes + 4 + 15) // 16 * 16
         self.rec = rec
         self.commits = torch.zeros(13 * rec, dtype=torch.uint8, device="cuda")
+        self.evals = torch.zeros(10 * 4, dtype=torch.int64, device="cuda")
 
     # ---- helpers ------------------------------------------------------------------------------
     def _commit(self, slot: int, ptr: int, length: int):
@@ -141,13 +142,11 @@ class TurboPlonkHotPath:
         L.msm_batch_device(self.srs, [self.quot.data_ptr() + j * (n + 2) * 32 for j in range(W)], [n + 2] * W,
                            self.commits.data_ptr() + 6 * self.rec, stream=st)
         # Round 4 (prover.rs:205-229): evaluations of wires (5), sigmas (4) at zeta and z at zeta*omega
-        for j in range(W):
-            L.poly_divide_linear_device(c, self.wire_polys[j].data_ptr(), n + 2, self.zeta, self.scratch.data_ptr(),
-                                        stream=st)
-        for j in range(W - 1):
-            L.poly_divide_linear_device(c, self.sigmas[j].data_ptr(), n, self.zeta, self.scratch.data_ptr(), stream=st)
-        L.poly_divide_linear_device(c, self.perm_poly.data_ptr(), n + 3, self.zeta_omega, self.scratch.data_ptr(),
-                                    stream=st)
+        L.poly_eval_batch_device(c, [self.wire_polys[j].data_ptr() for j in range(W)]
+                                 + [self.sigmas[j].data_ptr() for j in range(W - 1)], [n + 2] * W + [n] * (W - 1),
+                                 self.zeta, self.evals.data_ptr(), stream=st)
+        L.poly_eval_batch_device(c, [self.perm_poly.data_ptr()], [n + 3], self.zeta_omega,
+                                 self.evals.data_ptr() + 9 * 32, stream=st)
         # linearisation polynomial (prover.rs:299-352, 946-1087): 13 selectors, z, last sigma, 5 quotient chunks
         ptrs = [self.selectors[j].data_ptr() for j in range(NUM_SELECTORS)]
         lens = [n] * NUM_SELECTORS

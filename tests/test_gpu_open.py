@@ -77,3 +77,22 @@ def test_device_polynomial_glue(hip, cv):
     q, ev = C.open_witness(cv.curve_id, exp, z)
     assert (r[0] == ev).all() and (r[1:] == q).all()
     st.close()
+
+
+@pytest.mark.parametrize("lens", [[1], [63, 64, 65], [4096, 4097, 1, 0, 300000]])
+def test_poly_eval_batch(hip, lens):
+    import torch
+
+    cv = R.BN254
+    polys = [rand_fr_mont(cv, max(l, 1), 80 + i)[:l] for i, l in enumerate(lens)]
+    dev = [torch.from_numpy(np.ascontiguousarray(p).view(np.int64).reshape(-1)).cuda() if len(p) else
+           torch.zeros(4, dtype=torch.int64, device="cuda") for p in polys]
+    z = rand_fr_mont(cv, 1, 81)[0]
+    out = torch.full((len(lens) * 4,), 7, dtype=torch.int64, device="cuda")
+    st = hip.Stream()
+    hip.poly_eval_batch_device(0, [d.data_ptr() for d in dev], lens, z, out.data_ptr(), stream=st)
+    st.sync()
+    got = out.cpu().numpy().view(np.uint64).reshape(len(lens), 4)
+    for i, p in enumerate(polys):
+        assert (got[i] == C.poly_eval(0, p, z)).all(), lens[i]
+    st.close()

@@ -73,6 +73,13 @@ def test_prover_path_matches_oracle(hip, cv):
     opening = lincomb([lin] + wire_polys + list(sig_c[:4]), lc, n + 3)
     q, _ = C.open_witness(cid, opening, rand(1, 19)[0])
     assert (got[11] == C.msm(cid, srs_host[:n + 2], q)).all()
+    # round-4 evaluations
+    ev = hp.evals.cpu().numpy().view(np.uint64).reshape(10, 4)
+    for j in range(5):
+        assert (ev[j] == C.poly_eval(cid, wire_polys[j], rand(1, 19)[0])).all()
+    for j in range(4):
+        assert (ev[5 + j] == C.poly_eval(cid, sig_c[j], rand(1, 19)[0])).all()
+    assert (ev[9] == C.poly_eval(cid, perm_poly, rand(1, 20)[0])).all()
     q2, _ = C.open_witness(cid, perm_poly, rand(1, 20)[0])
     assert (got[12] == C.msm(cid, srs_host[:n + 2], q2)).all()
     srs.free()
