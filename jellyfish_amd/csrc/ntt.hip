@@ -13,6 +13,8 @@
 // The last pass performs the digit-reversal as a transposed store whose inner run is the
 // first digit, so stores stay in 2^d-element-aligned contiguous segments.  The coset
 // pre-scale / inverse post-scale are fused into the first load / last store.
+#include <stdlib.h>
+
 #include <map>
 #include <mutex>
 
@@ -28,7 +30,7 @@ constexpr int NTT_THREADS = 256;
 
 struct NttTables {
     uint32_t* params = nullptr;    // [0] w_n  [1] w_256  [2] n^-1  [3] h (or h^-1)   (8 limbs each)
-    uint32_t* tw_small = nullptr;  // w_256^k, k < 128
+    uint32_t* tw_small = nullptr;  // w_256^k, k < 256
     uint32_t* tl = nullptr;        // w_n^i, i < 2^a
     uint32_t* th = nullptr;        // w_n^(i 2^a), i < 2^(log_n - a)
     uint32_t* cl = nullptr;        // h^i
@@ -268,6 +270,350 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(NttPass P) {
     }
 }
 
+// ---- register-radix digit pass (digits of 5..8 bits, at least two passes) ----------------------
+//
+// Same tile, same global addressing and the same result as k_ntt_pass, but the 2^d-point column
+// transforms run as three Cooley-Tukey stages of radix <= 8 held in registers (8 elements per lane),
+// exchanged through LDS twice per tile instead of once per butterfly layer:
+//   j = ja + RA*jb + RA*RB*jc  ->  k = kc + 8*kb + 8*RB*ka
+//   stage 1: DFT_8 over jc                       (lane = (ja, jb, col))
+//   stage 2: * w_D^(RA*jb*kc), DFT_RB over jb    (lane = (ja, kc, col))
+//   stage 3: * w_D^(ja*(kc+8*kb)), DFT_RA over ja (lane = (kb, kc, col))
+// A digit shorter than 3 bits fills its lane's 8 registers with adjacent column groups.  Every
+// factor is a power of w_256 (table in LDS).  Exchanges use two 16-byte planes with a row pitch
+// of 257 entries, so readers (consecutive lanes -> consecutive entries) and writers are
+// bank-conflict free.  Zero extension (first pass, only the jc = 0 rows non-zero, the PLONK 8n
+// coset shape): stage 1 degenerates to a broadcast, one load per lane.
+template <class Fr>
+JF_DEV void ntt_bfly(Fp<Fr>& a, Fp<Fr>& b) {
+    Fp<Fr> t = fp_add<Fr>(a, b);
+    b = fp_sub<Fr>(a, b);
+    a = t;
+}
+// opaque copy of an index: keeps loop-invariant twiddle loads inside the per-polynomial loop (hoisted
+// out of it they would pin ~130 registers and spill)
+JF_DEV uint32_t launder(uint32_t x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+template <class Fr>
+JF_DEV Fp<Fr> lds_get(const uint4* pl, const uint4* ph, uint32_t idx) {
+    Fp<Fr> x;
+    uint4 a = pl[idx], b = ph[idx];
+    x.v[0] = a.x, x.v[1] = a.y, x.v[2] = a.z, x.v[3] = a.w;
+    x.v[4] = b.x, x.v[5] = b.y, x.v[6] = b.z, x.v[7] = b.w;
+    return x;
+}
+template <class Fr>
+JF_DEV void lds_put(uint4* pl, uint4* ph, uint32_t idx, const Fp<Fr>& x) {
+    pl[idx] = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
+    ph[idx] = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
+}
+
+// natural-order DFT of size 4: Y[k] = sum_j b_j w4^(jk); constants come from the w_256 table in LDS
+// right where they are used (short live ranges)
+template <class Fr>
+JF_DEV void ntt_dft4(Fp<Fr>& b0, Fp<Fr>& b1, Fp<Fr>& b2, Fp<Fr>& b3, const uint4* twl, const uint4* twh) {
+    ntt_bfly<Fr>(b0, b2);
+    ntt_bfly<Fr>(b1, b3);
+    b3 = fp_mul<Fr>(b3, lds_get<Fr>(twl, twh, launder(64)));
+    ntt_bfly<Fr>(b0, b1);
+    ntt_bfly<Fr>(b2, b3);
+    Fp<Fr> t = b1;  // (Y0, Y2, Y1, Y3) -> natural order
+    b1 = b2;
+    b2 = t;
+}
+template <class Fr>
+JF_DEV void ntt_dft8(Fp<Fr> (&a)[8], const uint4* twl, const uint4* twh) {
+    ntt_dft4<Fr>(a[0], a[2], a[4], a[6], twl, twh);
+    ntt_dft4<Fr>(a[1], a[3], a[5], a[7], twl, twh);
+    a[3] = fp_mul<Fr>(a[3], lds_get<Fr>(twl, twh, launder(32)));
+    a[5] = fp_mul<Fr>(a[5], lds_get<Fr>(twl, twh, launder(64)));
+    a[7] = fp_mul<Fr>(a[7], lds_get<Fr>(twl, twh, launder(96)));
+    ntt_bfly<Fr>(a[0], a[1]);
+    ntt_bfly<Fr>(a[2], a[3]);
+    ntt_bfly<Fr>(a[4], a[5]);
+    ntt_bfly<Fr>(a[6], a[7]);
+    // X0..X3 = a0,a2,a4,a6 ; X4..X7 = a1,a3,a5,a7
+    Fp<Fr> t1 = a[1], t2 = a[2], t3 = a[3], t4 = a[4], t5 = a[5], t6 = a[6];
+    a[1] = t2;
+    a[2] = t4;
+    a[3] = t6;
+    a[4] = t1;
+    a[5] = t3;
+    a[6] = t5;
+}
+// 2^(3-X) independent natural-order DFTs of size 2^X on registers r = digit | group << X
+template <class Fr, int X>
+JF_DEV void ntt_dft_regs(Fp<Fr> (&v)[8], const uint4* twl, const uint4* twh);
+
+template <class Fr, int X>
+JF_DEV void ntt_dft_regs(Fp<Fr> (&v)[8], const uint4* twl, const uint4* twh) {
+    static_assert(Fr::N == 8, "register-radix NTT assumes 8-limb scalars");
+    if constexpr (X == 3) {
+        ntt_dft8<Fr>(v, twl, twh);
+    } else if constexpr (X == 2) {
+        ntt_dft4<Fr>(v[0], v[1], v[2], v[3], twl, twh);
+        ntt_dft4<Fr>(v[4], v[5], v[6], v[7], twl, twh);
+    } else if constexpr (X == 1) {
+        ntt_bfly<Fr>(v[0], v[1]);
+        ntt_bfly<Fr>(v[2], v[3]);
+        ntt_bfly<Fr>(v[4], v[5]);
+        ntt_bfly<Fr>(v[6], v[7]);
+    }
+}
+
+template <class Fr, int DB>
+__global__ __launch_bounds__(NTT_THREADS, 2) void k_ntt_pass_r8(NttPass P) {
+    constexpr int N = Fr::N;
+    constexpr int XB = (DB - 3 >= 3) ? 3 : DB - 3, XA = DB - 3 - XB;
+    constexpr int RA = 1 << XA, RB = 1 << XB;
+    constexpr int LOGC = NTT_TILE_LOG - DB, C = 1 << LOGC;
+    constexpr int F2 = 3 - XB, F3 = 3 - XA;            // register bits not used by the digit: column groups
+    constexpr int LC2 = LOGC - F2, LC3 = LOGC - F3;    // column bits carried by the lane index
+    constexpr int PITCH = 257;
+    static_assert(DB >= 5 && DB <= 8 && XA <= 2 && LC2 >= 0 && (XA == 0 || LC3 >= 0), "digit plan");
+    __shared__ uint4 xl[8 * PITCH], xh[8 * PITCH], twl[256], twh[256];
+
+    const uint32_t tid = threadIdx.x;
+    lds_put<Fr>(twl, twh, tid, fp_load<Fr>(P.t.tw_small + tid * N));
+
+    const uint32_t d = DB;
+    const uint64_t ncols = (uint64_t)P.outer << (P.log_n - d);
+    const uint64_t g0 = (uint64_t)blockIdx.x << LOGC;
+    const uint32_t log_S = P.log_M - d;
+    const uint32_t log_rows = P.log_n - P.log_M;
+    const uint64_t n = 1ull << P.log_n;
+    const size_t poly_stride = (size_t)n * N;
+    const bool jfast = P.final != 0;  // final pass: rows are contiguous, lanes run along j on the load side
+
+    auto col_base = [&](uint64_t g, uint32_t& poly, uint64_t& base, uint32_t& jrest) {
+        jrest = (uint32_t)(g & ((1ull << log_S) - 1));
+        uint64_t row = (g >> log_S) & ((1ull << log_rows) - 1);
+        poly = (uint32_t)(g >> (log_S + log_rows));
+        base = (row << P.log_M) + jrest;
+    };
+    const uint32_t R1bits = P.dig[0];
+    const uint32_t log_NR = P.log_n - d;
+    auto final_col = [&](uint64_t g, uint32_t& poly, uint64_t& row, uint64_t& outbase) {
+        uint32_t k1 = (uint32_t)(g & ((1ull << R1bits) - 1));
+        uint64_t rest = (g >> R1bits) & ((1ull << (log_NR - R1bits)) - 1);
+        poly = (uint32_t)(g >> log_NR);
+        row = ((uint64_t)k1 << (log_NR - R1bits)) + rest;
+        uint64_t rev = 0;
+        uint32_t shift = 0, consumed = 0;
+        uint32_t rest_bits = log_NR - R1bits;
+        for (uint32_t q = 1; q + 1 < P.ndig; q++) {
+            uint32_t bq = P.dig[q];
+            consumed += bq;
+            uint64_t kq = (rest >> (rest_bits - consumed)) & ((1ull << bq) - 1);
+            rev |= kq << shift;
+            shift += bq;
+        }
+        outbase = k1 + (rev << R1bits);
+    };
+
+    // ---- lane coordinates in the three stages ----------------------------------------------------
+    uint32_t col1, ja1, jb1;
+    if (!jfast) {
+        col1 = tid & (C - 1);
+        ja1 = (tid >> LOGC) & (RA - 1);
+        jb1 = tid >> (LOGC + XA);
+    } else {
+        ja1 = tid & (RA - 1);
+        jb1 = (tid >> XA) & (RB - 1);
+        col1 = tid >> (XA + XB);
+    }
+    // stage 2 keeps the column-fastest lane order when it is also the storing stage (XA == 0)
+    const bool jfast2 = jfast && XA > 0;
+    uint32_t coll2, kc2, ja2;
+    if (!jfast2) {
+        coll2 = tid & ((1u << LC2) - 1);
+        kc2 = (tid >> LC2) & 7;
+        ja2 = tid >> (LC2 + 3);
+    } else {
+        ja2 = tid & (RA - 1);
+        kc2 = (tid >> XA) & 7;
+        coll2 = tid >> (XA + 3);
+    }
+    const uint32_t coll3 = tid & ((1u << (XA ? LC3 : 0)) - 1);
+    const uint32_t kc3 = (tid >> (XA ? LC3 : 0)) & 7;
+    const uint32_t kb3 = tid >> ((XA ? LC3 : 0) + 3);
+
+    // ---- zero-extension: only rows jc = 0 carry data -> stage 1 is a broadcast -------------------
+    bool zext = false;
+    if (P.first && P.in_len < n && (uint64_t)C <= (1ull << log_S)) {
+        uint64_t jrest0 = g0 & ((1ull << log_S) - 1);
+        uint64_t nz = (P.in_len > jrest0) ? (((uint64_t)P.in_len - 1 - jrest0) >> log_S) + 1 : 1;
+        zext = nz <= (uint64_t)(RA * RB);
+    }
+    const bool has_cf = P.first && !P.inverse && P.t.scale_mode == 2;
+
+    // ---- load descriptors (stage-1 lane: 8 rows jc of one column) ---------------------------------
+    uint32_t ld_off[8];
+    uint32_t ld_idx0 = 0, ld_step = 0;  // element index inside the polynomial of register 0, step per register
+    uint32_t ld_mask = 0;
+    Fp<Fr> cf0 = Fp<Fr>::zero();
+    {
+        const uint64_t g = g0 + col1;
+        const uint32_t j1 = ja1 + (jb1 << XA);
+        uint32_t poly = 0;
+        uint64_t idx0 = 0, step = 0;
+        if (g < ncols) {
+            if (!P.final) {
+                uint64_t base;
+                uint32_t jrest;
+                col_base(g, poly, base, jrest);
+                idx0 = base + ((uint64_t)j1 << log_S);
+                step = 1ull << (XA + XB + log_S);
+            } else {
+                uint64_t row, ob;
+                final_col(g, poly, row, ob);
+                idx0 = (row << d) + j1;
+                step = 1ull << (XA + XB);
+            }
+        }
+        ld_idx0 = (uint32_t)idx0;
+        ld_step = (uint32_t)step;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            uint64_t idx = idx0 + (uint64_t)r * step;
+            bool ok = (g < ncols) && (!P.first || idx < P.in_len);
+            ld_off[r] = ok ? (uint32_t)((uint64_t)poly * n + idx) : 0u;
+            ld_mask |= ok ? (1u << r) : 0u;
+        }
+        if (has_cf && zext && (ld_mask & 1u)) cf0 = two_level<Fr>(P.t.cl, P.t.ch, P.t.a, idx0);
+    }
+
+    // ---- store descriptors (last stage's lane layout) ---------------------------------------------
+    uint32_t st_off[8];
+    uint32_t st_mask = 0, tw_mask = 0;
+    Fp<Fr> tw[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        uint32_t k, col;
+        if constexpr (XA > 0) {
+            col = ((uint32_t)(r >> XA) << LC3) | coll3;
+            k = kc3 + (kb3 << 3) + ((uint32_t)(r & (RA - 1)) << (3 + XB));
+        } else {
+            col = ((uint32_t)(r >> XB) << LC2) | coll2;
+            k = kc2 + ((uint32_t)(r & (RB - 1)) << 3);
+        }
+        const uint64_t g = g0 + col;
+        st_off[r] = 0;
+        tw[r] = Fp<Fr>::zero();
+        if (g < ncols) {
+            st_mask |= 1u << r;
+            uint32_t poly;
+            uint64_t pos;
+            if (!P.final) {
+                uint64_t base;
+                uint32_t jrest;
+                col_base(g, poly, base, jrest);
+                pos = base + ((uint64_t)k << log_S);
+                uint64_t E = ((uint64_t)k * jrest) << log_rows;
+                if (E) {
+                    tw_mask |= 1u << r;
+                    tw[r] = two_level<Fr>(P.t.tl, P.t.th, P.t.a, E);
+                }
+            } else {
+                uint64_t row, ob;
+                final_col(g, poly, row, ob);
+                pos = ob + ((uint64_t)k << log_NR);
+                if (P.inverse && P.t.scale_mode == 1) {
+                    tw_mask |= 1u << r;
+                    tw[r] = fp_load<Fr>(P.t.params + 2 * N);
+                } else if (P.inverse && P.t.scale_mode == 2) {
+                    tw_mask |= 1u << r;
+                    tw[r] = two_level<Fr, true>(P.t.cl, P.t.ch, P.t.a, pos);
+                }
+            }
+            st_off[r] = (uint32_t)((uint64_t)poly * n + pos);
+        }
+    }
+    __syncthreads();  // w_256 table visible
+
+    for (uint32_t b = 0; b < P.inner; b++) {
+        const uint32_t* src = P.src + (size_t)b * poly_stride;
+        uint32_t* dst = P.dst + (size_t)b * poly_stride;
+        Fp<Fr> v[8];
+        if (!zext) {
+            // ---- stage 1: DFT_8 over jc ------------------------------------------------------------
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                v[r] = Fp<Fr>::zero();
+                if ((ld_mask >> r) & 1u) {
+                    v[r] = fp_load<Fr>(src + (size_t)ld_off[r] * N);
+                    if (has_cf) v[r] = fp_mul<Fr>(v[r], two_level<Fr>(P.t.cl, P.t.ch, P.t.a, ld_idx0 + (uint32_t)r * ld_step));
+                }
+            }
+            ntt_dft_regs<Fr, 3>(v, twl, twh);
+            {
+                const uint32_t fill2 = col1 >> LC2, cw = col1 & ((1u << LC2) - 1);
+                const uint32_t r2 = jb1 | (fill2 << XB);
+                const uint32_t t2 = jfast2 ? (ja1 | (cw << (XA + 3))) : (cw | (ja1 << (LC2 + 3)));
+                const uint32_t sh = jfast2 ? XA : LC2;
+#pragma unroll
+                for (int r = 0; r < 8; r++) lds_put<Fr>(xl, xh, r2 * PITCH + t2 + ((uint32_t)r << sh), v[r]);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 8; r++) v[r] = lds_get<Fr>(xl, xh, r * PITCH + tid);
+        } else {
+            Fp<Fr> x = Fp<Fr>::zero();
+            if (ld_mask & 1u) {
+                x = fp_load<Fr>(src + (size_t)ld_off[0] * N);
+                if (has_cf) x = fp_mul<Fr>(x, cf0);
+            }
+            lds_put<Fr>(xl, xh, tid, x);  // first pass is never final: entry = col | ja << LOGC | jb << (LOGC + XA)
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const uint32_t col = ((uint32_t)(r >> XB) << LC2) | coll2;
+                v[r] = lds_get<Fr>(xl, xh, col | (ja2 << LOGC) | ((uint32_t)(r & (RB - 1)) << (LOGC + XA)));
+            }
+        }
+        // ---- stage 2: * w_D^(RA jb kc), DFT_RB over jb ----------------------------------------------
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const uint32_t jb = r & (RB - 1);
+            if (jb) v[r] = fp_mul<Fr>(v[r], lds_get<Fr>(twl, twh, launder((jb * kc2) << (XA + 8 - DB))));
+        }
+        ntt_dft_regs<Fr, XB>(v, twl, twh);
+        if constexpr (XA > 0) {
+            __syncthreads();  // exchange-1 reads done
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const uint32_t kb = r & (RB - 1);
+                const uint32_t col = ((uint32_t)(r >> XB) << LC2) | coll2;
+                const uint32_t r3 = ja2 | ((col >> LC3) << XA);
+                const uint32_t t3 = (col & ((1u << LC3) - 1)) | (kc2 << LC3) | (kb << (LC3 + 3));
+                lds_put<Fr>(xl, xh, r3 * PITCH + t3, v[r]);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 8; r++) v[r] = lds_get<Fr>(xl, xh, r * PITCH + tid);
+            // ---- stage 3: * w_D^(ja (kc + 8 kb)), DFT_RA over ja ------------------------------------
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const uint32_t ja = r & (RA - 1);
+                if (ja) v[r] = fp_mul<Fr>(v[r], lds_get<Fr>(twl, twh, launder((ja * (kc3 + (kb3 << 3))) << (8 - DB))));
+            }
+            ntt_dft_regs<Fr, XA>(v, twl, twh);
+        }
+        // ---- store ------------------------------------------------------------------------------------
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            if ((st_mask >> r) & 1u) {
+                Fp<Fr> x = v[r];
+                if ((tw_mask >> r) & 1u) x = fp_mul<Fr>(x, tw[r]);
+                fp_store<Fr>(dst + (size_t)st_off[r] * N, x);
+            }
+        }
+        __syncthreads();  // LDS free for the next polynomial
+    }
+}
+
 // ---- table construction ----------------------------------------------------------------------
 template <class Fr>
 struct RootConst;
@@ -349,7 +695,7 @@ static int32_t build_tables(uint32_t log_n, int inverse, const uint64_t* coset_m
     t.scale_mode = has_coset ? 2 : (inverse ? 1 : 0);
     uint32_t* d_coset = nullptr;
     JF_HIP(hipMalloc(&t.params, 4 * N * 4));
-    JF_HIP(hipMalloc(&t.tw_small, 128 * N * 4));
+    JF_HIP(hipMalloc(&t.tw_small, 256 * N * 4));
     JF_HIP(hipMalloc(&t.tl, (size_t)lo_n * N * 4));
     JF_HIP(hipMalloc(&t.th, (size_t)hi_n * N * 4));
     if (has_coset) {
@@ -361,7 +707,7 @@ static int32_t build_tables(uint32_t log_n, int inverse, const uint64_t* coset_m
     hipLaunchKernelGGL((k_ntt_params<Fr>), dim3(1), dim3(64), 0, st->s, log_n, inverse, d_coset, (int)has_coset,
                        t.params);
     hipLaunchKernelGGL((k_pow_table<Fr>), dim3(1), dim3(256), 0, st->s, t.params + N, (const uint32_t*)nullptr,
-                       (uint64_t)1, 128u, t.tw_small);
+                       (uint64_t)1, 256u, t.tw_small);
     hipLaunchKernelGGL((k_pow_table<Fr>), dim3((lo_n + 255) / 256), dim3(256), 0, st->s, t.params,
                        (const uint32_t*)nullptr, (uint64_t)1, lo_n, t.tl);
     hipLaunchKernelGGL((k_pow_table<Fr>), dim3((hi_n + 255) / 256), dim3(256), 0, st->s, t.params,
@@ -448,6 +794,11 @@ static int32_t ntt_device_t(int32_t curve, uint32_t* d_data, uint32_t log_n, siz
     uint32_t dig[4] = {0, 0, 0, 0};
     for (uint32_t p = 0; p < ndig; p++) dig[p] = log_n / ndig + (p < log_n % ndig ? 1 : 0);
 
+    // register-radix passes need >= 2 passes of 5..8 bits; tiny transforms keep the layer-per-exchange kernel
+    static const bool force_v1 = getenv("JFHIP_NTT_V1") != nullptr;
+    bool use_r8 = ndig >= 2 && !force_v1;
+    for (uint32_t p = 0; p < ndig; p++) use_r8 = use_r8 && dig[p] >= 5 && dig[p] <= 8;
+
     uint32_t* tmp = nullptr;
     if (ndig >= 2) {
         JF_TRY(st->ntt_tmp.ensure(batch * n * N * 4));
@@ -475,7 +826,18 @@ static int32_t ntt_device_t(int32_t curve, uint32_t* d_data, uint32_t log_n, siz
         uint64_t ncols = (uint64_t)P.outer << (log_n - dig[p]);
         uint32_t logC = NTT_TILE_LOG - dig[p];
         uint64_t blocks = (ncols + (1ull << logC) - 1) >> logC;
-        hipLaunchKernelGGL((k_ntt_pass<Fr>), dim3((unsigned)blocks), dim3(NTT_THREADS), 0, st->s, P);
+        if (use_r8) {
+            switch (dig[p]) {
+#ifndef JF_NTT_QUICK
+                case 5: hipLaunchKernelGGL((k_ntt_pass_r8<Fr, 5>), dim3((unsigned)blocks), dim3(NTT_THREADS), 0, st->s, P); break;
+                case 6: hipLaunchKernelGGL((k_ntt_pass_r8<Fr, 6>), dim3((unsigned)blocks), dim3(NTT_THREADS), 0, st->s, P); break;
+                case 7: hipLaunchKernelGGL((k_ntt_pass_r8<Fr, 7>), dim3((unsigned)blocks), dim3(NTT_THREADS), 0, st->s, P); break;
+#endif
+                default: hipLaunchKernelGGL((k_ntt_pass_r8<Fr, 8>), dim3((unsigned)blocks), dim3(NTT_THREADS), 0, st->s, P); break;
+            }
+        } else {
+            hipLaunchKernelGGL((k_ntt_pass<Fr>), dim3((unsigned)blocks), dim3(NTT_THREADS), 0, st->s, P);
+        }
         JF_HIP(hipGetLastError());
         pt.mark();
         log_M -= dig[p];
