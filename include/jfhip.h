@@ -180,6 +180,20 @@ int32_t jfhip_plonk_quotient_turbo_device(int32_t curve_id, uint32_t log_n, uint
                                           const void *d_pub_input, const uint64_t *k_mont,
                                           const uint64_t *challenges_mont, void *d_quot, jfhip_stream *stream);
 
+/* UltraPlonk (Plookup) variant of the same loop: 6 wire types, 14 selectors (the reference's order with
+ * q_lookup last, relation/src/constraint_system.rs:1091-1107), 6 sigmas, and the Plookup part
+ * compute_quotient_plookup_contribution (prover.rs:766-882, eval_merged_table /
+ * eval_merged_lookup_witness plonk/src/proof_system/structs.rs:899-931):
+ *     d_quot[i] += alpha_base * ((t_circ + t_perm_1 + t_lookup_1) * z_h_inv[i mod (m/n)] + t_perm_2 + t_lookup_2)
+ * d_plookup: 7 polys [range_table, key_table, table_dom_sep, q_dom_sep, h_1, h_2, prod_lookup]
+ * (the coset FFTs of prover.rs:559-573).  k_mont: 6 coset representatives; challenges_mont: alpha, beta,
+ * gamma, tau, alpha_base (5 x 4 limbs).  For batch_prove the caller advances alpha_base by alpha^7 per
+ * instance (prover.rs:651-655).  Asynchronous on `stream`. */
+int32_t jfhip_plonk_quotient_ultra_device(int32_t curve_id, uint32_t log_n, uint32_t log_m, const void *d_selectors,
+                                          const void *d_sigmas, const void *d_wires, const void *d_prod_perm,
+                                          const void *d_pub_input, const void *d_plookup, const uint64_t *k_mont,
+                                          const uint64_t *challenges_mont, void *d_quot, jfhip_stream *stream);
+
 /* ---- device-resident polynomial glue (next row) -------------------------- */
 
 /* Replaces the witness-polynomial division of open() / compute_batched_witness_polynomial_commitment

@@ -653,6 +653,22 @@ int32_t jfhip_plonk_quotient_turbo_device(int32_t curve_id, uint32_t log_n, uint
                                        k_mont, ch, (uint32_t*)d_quot, st);
 }
 
+int32_t jfhip_plonk_quotient_ultra_device(int32_t curve_id, uint32_t log_n, uint32_t log_m, const void* d_sel,
+                                          const void* d_sig, const void* d_wires, const void* d_zperm,
+                                          const void* d_pi, const void* d_plookup, const uint64_t* k_mont,
+                                          const uint64_t* ch, void* d_quot, jfhip_stream* stream) {
+    JF_TRY(check_curve(curve_id));
+    if (!d_sel || !d_sig || !d_wires || !d_zperm || !d_pi || !d_plookup || !k_mont || !ch || !d_quot) {
+        set_error("null argument");
+        return JFHIP_ERR_INVALID;
+    }
+    JF_STREAM(st, stream);
+    std::lock_guard<std::mutex> lk(st->mu);
+    return plonk_quotient_ultra_device(curve_id, log_n, log_m, (const uint32_t*)d_sel, (const uint32_t*)d_sig,
+                                       (const uint32_t*)d_wires, (const uint32_t*)d_zperm, (const uint32_t*)d_pi,
+                                       (const uint32_t*)d_plookup, k_mont, ch, (uint32_t*)d_quot, st);
+}
+
 int32_t jfhip_poly_divide_linear_device(int32_t curve_id, const void* d_coeffs, size_t n, const uint64_t* point,
                                         void* d_out, jfhip_stream* stream) {
     JF_TRY(check_curve(curve_id));

@@ -34,7 +34,7 @@ def lib():
         _LIB = ctypes.CDLL(so)
         for name in ("jfo_fp_binop", "jfo_fp_unop", "jfo_ec_add", "jfo_ec_mul", "jfo_ec_on_curve", "jfo_srs_gen",
                      "jfo_msm", "jfo_msm_naive", "jfo_poly_eval", "jfo_open_witness", "jfo_ntt", "jfo_domain_root",
-                     "jfo_threads", "jfo_field_limbs", "jfo_plonk_quotient_turbo"):
+                     "jfo_threads", "jfo_field_limbs", "jfo_plonk_quotient_turbo", "jfo_plonk_quotient_ultra"):
             getattr(_LIB, name).restype = ctypes.c_int
     return _LIB
 
@@ -157,6 +157,21 @@ def plonk_quotient_turbo(curve: int, log_n: int, log_m: int, sel, sig, wires, zp
     assert lib().jfo_plonk_quotient_turbo(curve, log_n, log_m, 5, _p(sel), _p(sig), _p(wires), _p(zperm), _p(pi), _p(k),
                                           _p(alpha), _p(beta), _p(gamma), _p(alpha_base), _p(o),
                                           threads or nthreads()) == 0
+    return o
+
+
+def plonk_quotient_ultra(curve: int, log_n: int, log_m: int, sel, sig, wires, zperm, pi, lookup, k, alpha, beta, gamma,
+                         tau, alpha_base, out=None, threads: int = 0):
+    """UltraPlonk: sel [14][m][4] (q_lookup last), sig/wires [6][m][4], lookup [7][m][4] in the order
+    range_table, key_table, table_dom_sep, q_dom_sep, h1, h2, prod_lookup; returns out (+= alpha_base * t)."""
+    m = 1 << log_m
+    sel, sig, wires, zperm, pi, lookup = (_u64(x) for x in (sel, sig, wires, zperm, pi, lookup))
+    assert sel.size == 14 * m * 4 and sig.size == 6 * m * 4 and wires.size == 6 * m * 4 and lookup.size == 7 * m * 4
+    k, alpha, beta, gamma, tau, alpha_base = (_u64(x) for x in (k, alpha, beta, gamma, tau, alpha_base))
+    o = np.zeros((m, 4), dtype=np.uint64) if out is None else np.array(out, dtype=np.uint64, copy=True)
+    assert lib().jfo_plonk_quotient_ultra(curve, log_n, log_m, _p(sel), _p(sig), _p(wires), _p(zperm), _p(pi),
+                                          _p(lookup), _p(k), _p(alpha), _p(beta), _p(gamma), _p(tau), _p(alpha_base),
+                                          _p(o), threads or nthreads()) == 0
     return o
 
 

@@ -499,12 +499,13 @@ int jfo_threads(void) { return omp_get_max_threads(); }
  * All arrays are coset evaluations over the size-m quotient domain (coset offset = Fr::GENERATOR),
  * laid out [poly][m]; 13 selectors in the reference's order q_lc[4], q_mul[2], q_hash[4], q_o, q_c,
  * q_ecc; nw wire types (5); k[nw] coset representatives; every element Montgomery. */
-int jfo_plonk_quotient_turbo(int curve, int log_n, int log_m, int nw, const uint64_t *sel, const uint64_t *sig,
-                             const uint64_t *wires, const uint64_t *zperm, const uint64_t *pi, const uint64_t *k,
-                             const uint64_t *alpha, const uint64_t *beta, const uint64_t *gamma,
-                             const uint64_t *alpha_base, uint64_t *out, int threads) {
+static int quot_core(int curve, int log_n, int log_m, int nw, const uint64_t *sel, const uint64_t *sig,
+                     const uint64_t *wires, const uint64_t *zperm, const uint64_t *pi, const uint64_t *lookup,
+                     const uint64_t *k, const uint64_t *alpha, const uint64_t *beta, const uint64_t *gamma,
+                     const uint64_t *tau, const uint64_t *alpha_base, uint64_t *out, int threads) {
     ensure_init();
-    if ((curve != 0 && curve != 1) || nw != 5 || log_m < log_n) return -1;
+    if ((curve != 0 && curve != 1) || (nw != 5 && nw != 6) || log_m < log_n) return -1;
+    if ((nw == 6) != (lookup != NULL)) return -1;
     if (threads < 1) threads = 1;
     const f4_ctx *fr = fr_of(curve);
     const size_t n = (size_t)1 << log_n, m = (size_t)1 << log_m, ratio = m / n;
@@ -514,6 +515,9 @@ int jfo_plonk_quotient_turbo(int curve, int log_n, int log_m, int nw, const uint
     memcpy(one, fr->r1, 32);
     f4_from_u64(fr, nn, (uint64_t)n);
     f4_sqr(fr, alpha2, alpha);
+    uint64_t wn_inv[4];
+    domain_gen(curve, log_n, wn_inv);
+    f4_inv(fr, wn_inv, wn_inv);
     /* z_h_inv[i] = 1 / ((g w^i)^n - 1), i < ratio   (prover.rs:509-516) */
     uint64_t *zh = (uint64_t *)malloc(32 * ratio);
     for (size_t i = 0; i < ratio; i++) {
@@ -527,10 +531,10 @@ int jfo_plonk_quotient_turbo(int curve, int log_n, int log_m, int nw, const uint
     }
 #pragma omp parallel for num_threads(threads) schedule(static)
     for (size_t i = 0; i < m; i++) {
-        uint64_t x[4], e[1] = {i}, t[4], u[4], acc[4], w[5][4];
+        uint64_t x[4], e[1] = {i}, t[4], u[4], acc[4], w[6][4];
         f4_pow(fr, x, wm, e, 1);
         f4_mul(fr, x, x, g); /* eval_point */
-        for (int j = 0; j < 5; j++) memcpy(w[j], wires + 4 * (j * m + i), 32);
+        for (int j = 0; j < nw; j++) memcpy(w[j], wires + 4 * (j * m + i), 32);
 #define SEL(j) (sel + 4 * ((size_t)(j) * m + i))
         /* gate part :665-699 */
         f4_add(fr, acc, SEL(11), pi + 4 * i); /* q_c + pi */
@@ -561,7 +565,7 @@ int jfo_plonk_quotient_turbo(int curve, int log_n, int log_m, int nw, const uint
         const uint64_t *zx = zperm + 4 * i, *zxw = zperm + 4 * ((i + ratio) % m);
         uint64_t r1[4], r1b[4];
         memcpy(r1, zx, 32);
-        for (int j = 0; j < 5; j++) {
+        for (int j = 0; j < nw; j++) {
             f4_mul(fr, t, k + 4 * j, x);
             f4_mul(fr, t, t, beta);
             f4_add(fr, t, t, w[j]);
@@ -570,7 +574,7 @@ int jfo_plonk_quotient_turbo(int curve, int log_n, int log_m, int nw, const uint
         }
         f4_mul(fr, r1, r1, alpha);
         memcpy(r1b, zxw, 32);
-        for (int j = 0; j < 5; j++) {
+        for (int j = 0; j < nw; j++) {
             f4_mul(fr, t, sig + 4 * (j * m + i), beta);
             f4_add(fr, t, t, w[j]);
             f4_add(fr, t, t, gamma);
@@ -585,8 +589,95 @@ int jfo_plonk_quotient_turbo(int curve, int log_n, int log_m, int nw, const uint
         f4_mul(fr, den, den, nn);
         f4_inv(fr, den, den);
         f4_mul(fr, r2, r2, den);
-        /* combine :636-641, :644-655 */
         f4_add(fr, acc, acc, r1);
+        if (lookup) {
+            /* Plookup part :766-882; lookup = [range_table, key_table, table_dom_sep, q_dom_sep, h1, h2, prod_lookup] */
+            const size_t nx = (i + ratio) % m;
+#define LK(p, idx) (lookup + 4 * ((size_t)(p) * m + (idx)))
+            const uint64_t *ql = sel + 4 * ((size_t)13 * m + i), *qlw = sel + 4 * ((size_t)13 * m + nx);
+            uint64_t wn3[4], wn4[4], mtx[4], mtxw[4], mlx[4], l1d[4], lnd[4], ap[4], b1[4], gb[4], s1[4], s2[4];
+            memcpy(wn3, wires + 4 * ((size_t)3 * m + nx), 32);
+            memcpy(wn4, wires + 4 * ((size_t)4 * m + nx), 32);
+            /* eval_merged_table (structs.rs:899-914) at x and at x * w */
+            f4_mul(fr, t, tau, w[4]);
+            f4_add(fr, t, t, w[3]);
+            f4_mul(fr, t, t, tau);
+            f4_add(fr, t, t, LK(1, i));
+            f4_mul(fr, t, t, tau);
+            f4_add(fr, t, t, LK(2, i));
+            f4_mul(fr, t, t, tau);
+            f4_mul(fr, t, t, ql);
+            f4_add(fr, mtx, t, LK(0, i));
+            f4_mul(fr, t, tau, wn4);
+            f4_add(fr, t, t, wn3);
+            f4_mul(fr, t, t, tau);
+            f4_add(fr, t, t, LK(1, nx));
+            f4_mul(fr, t, t, tau);
+            f4_add(fr, t, t, LK(2, nx));
+            f4_mul(fr, t, t, tau);
+            f4_mul(fr, t, t, qlw);
+            f4_add(fr, mtxw, t, LK(0, nx));
+            /* eval_merged_lookup_witness (structs.rs:916-931) */
+            f4_mul(fr, t, tau, w[2]);
+            f4_add(fr, t, t, w[1]);
+            f4_mul(fr, t, t, tau);
+            f4_add(fr, t, t, w[0]);
+            f4_mul(fr, t, t, tau);
+            f4_add(fr, t, t, LK(3, i));
+            f4_mul(fr, t, t, tau);
+            f4_mul(fr, t, t, ql);
+            f4_add(fr, mlx, t, w[5]);
+            /* L1(x)/Z_H(x) = 1/(n (x - 1)),  Ln(x)/Z_H(x) = w^-1 / (n (x - w^-1))   (lagrange.rs:89-115) */
+            f4_sub(fr, l1d, x, one);
+            f4_mul(fr, l1d, l1d, nn);
+            f4_inv(fr, l1d, l1d);
+            f4_sub(fr, lnd, x, wn_inv);
+            f4_mul(fr, lnd, lnd, nn);
+            f4_inv(fr, lnd, lnd);
+            f4_mul(fr, lnd, lnd, wn_inv);
+            uint64_t res2[4], p1[4];
+            f4_mul(fr, ap, alpha2, alpha); /* alpha^3 */
+            f4_sub(fr, t, LK(4, i), LK(5, nx));
+            f4_mul(fr, t, t, lnd);
+            f4_mul(fr, res2, t, ap);
+            f4_mul(fr, ap, ap, alpha);
+            f4_sub(fr, p1, LK(6, i), one);
+            f4_mul(fr, t, p1, l1d);
+            f4_mul(fr, t, t, ap);
+            f4_add(fr, res2, res2, t);
+            f4_mul(fr, ap, ap, alpha);
+            f4_mul(fr, t, p1, lnd);
+            f4_mul(fr, t, t, ap);
+            f4_add(fr, res2, res2, t);
+            f4_mul(fr, ap, ap, alpha); /* alpha^6 */
+            f4_add(fr, b1, one, beta);
+            f4_mul(fr, gb, b1, gamma);
+            /* p(x)(1+beta)(gamma + ml)(gb + mt_x + beta mt_xw) */
+            f4_mul(fr, s1, LK(6, i), b1);
+            f4_add(fr, t, gamma, mlx);
+            f4_mul(fr, s1, s1, t);
+            f4_mul(fr, t, beta, mtxw);
+            f4_add(fr, t, t, mtx);
+            f4_add(fr, t, t, gb);
+            f4_mul(fr, s1, s1, t);
+            /* p(xw)(gb + h1_x + beta h1_xw)(gb + h2_x + beta h2_xw) */
+            f4_mul(fr, t, beta, LK(4, nx));
+            f4_add(fr, t, t, LK(4, i));
+            f4_add(fr, t, t, gb);
+            f4_mul(fr, s2, LK(6, nx), t);
+            f4_mul(fr, t, beta, LK(5, nx));
+            f4_add(fr, t, t, LK(5, i));
+            f4_add(fr, t, t, gb);
+            f4_mul(fr, s2, s2, t);
+            f4_sub(fr, s1, s1, s2);
+            f4_sub(fr, t, x, wn_inv);
+            f4_mul(fr, s1, s1, t);
+            f4_mul(fr, s1, s1, ap);
+            f4_add(fr, acc, acc, s1);
+            f4_add(fr, r2, r2, res2);
+#undef LK
+        }
+        /* combine :636-641, :644-655 */
         f4_mul(fr, acc, acc, zh + 4 * (i % ratio));
         f4_add(fr, acc, acc, r2);
         f4_mul(fr, acc, acc, alpha_base);
@@ -594,4 +685,24 @@ int jfo_plonk_quotient_turbo(int curve, int log_n, int log_m, int nw, const uint
     }
     free(zh);
     return 0;
+}
+
+int jfo_plonk_quotient_turbo(int curve, int log_n, int log_m, int nw, const uint64_t *sel, const uint64_t *sig,
+                             const uint64_t *wires, const uint64_t *zperm, const uint64_t *pi, const uint64_t *k,
+                             const uint64_t *alpha, const uint64_t *beta, const uint64_t *gamma,
+                             const uint64_t *alpha_base, uint64_t *out, int threads) {
+    if (nw != 5) return -1;
+    return quot_core(curve, log_n, log_m, 5, sel, sig, wires, zperm, pi, NULL, k, alpha, beta, gamma, NULL, alpha_base,
+                     out, threads);
+}
+
+/* UltraPlonk: 6 wire types, 14 selectors (q_lookup last), lookup = 7 polys [range_table, key_table,
+ * table_dom_sep, q_dom_sep, h1, h2, prod_lookup]; adds prover.rs:766-882. */
+int jfo_plonk_quotient_ultra(int curve, int log_n, int log_m, const uint64_t *sel, const uint64_t *sig,
+                             const uint64_t *wires, const uint64_t *zperm, const uint64_t *pi, const uint64_t *lookup,
+                             const uint64_t *k, const uint64_t *alpha, const uint64_t *beta, const uint64_t *gamma,
+                             const uint64_t *tau, const uint64_t *alpha_base, uint64_t *out, int threads) {
+    if (!lookup || !tau) return -1;
+    return quot_core(curve, log_n, log_m, 6, sel, sig, wires, zperm, pi, lookup, k, alpha, beta, gamma, tau, alpha_base,
+                     out, threads);
 }

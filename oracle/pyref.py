@@ -421,3 +421,70 @@ def quotient_evals_turbo(cv: Curve, log_n: int, log_m: int, sel, sig, wires, zpe
         t = ((t_circ + t_perm_1) * zh_inv[i % ratio] + t_perm_2) % r
         out.append(alpha_base * t % r)
     return out
+
+
+# ----------------------------------------------------------------------------------
+# UltraPlonk (Plookup) quotient evaluations: the same loop with 6 wire types, 14 selectors
+# (the last is q_lookup) and compute_quotient_plookup_contribution,
+# plonk/src/proof_system/prover.rs:766-882 with eval_merged_table / eval_merged_lookup_witness
+# (plonk/src/proof_system/structs.rs:899-931) and first_and_last_lagrange_coeffs
+# (plonk/src/lagrange.rs:89-115).
+# ----------------------------------------------------------------------------------
+
+PLOOKUP_POLYS = ("range_table", "key_table", "table_dom_sep", "q_dom_sep", "h1", "h2", "prod_lookup")
+
+
+def quotient_evals_ultra(cv: Curve, log_n: int, log_m: int, sel, sig, wires, zperm, pi, lookup, k, alpha, beta, gamma,
+                         tau, alpha_base=1):
+    """sel: 14 lists (q_lookup last), sig/wires: 6 lists, lookup: 7 lists in PLOOKUP_POLYS order."""
+    r = cv.fr.p
+    n, m = 1 << log_n, 1 << log_m
+    ratio = m // n
+    wm = domain_root(cv, log_m)
+    wn_inv = pow(domain_root(cv, log_n), -1, r)
+    g = cv.fr_generator
+    zh_inv = [pow((pow(g * pow(wm, i, r) % r, n, r) - 1) % r, -1, r) for i in range(ratio)]
+    rng_t, key_t, tds, qds, h1, h2, pl = lookup
+    q_lookup = sel[13]
+    out = []
+    for i in range(m):
+        nx = (i + ratio) % m
+        x = g * pow(wm, i, r) % r
+        w = [wires[j][i] for j in range(6)]
+        wn = [wires[j][nx] for j in range(6)]
+        t_circ = (sel[11][i] + pi[i] + sum(sel[j][i] * w[j] for j in range(4)) + sel[4][i] * w[0] * w[1]
+                  + sel[5][i] * w[2] * w[3] + sel[12][i] * w[0] * w[1] * w[2] * w[3] * w[4]
+                  + sum(sel[6 + j][i] * pow(w[j], 5, r) for j in range(4)) - sel[10][i] * w[4]) % r
+        a = zperm[i]
+        for j in range(6):
+            a = a * (w[j] + k[j] * x * beta + gamma) % r
+        b = zperm[nx]
+        for j in range(6):
+            b = b * (w[j] + sig[j][i] * beta + gamma) % r
+        t_perm_1 = alpha * (a - b) % r
+        t_perm_2 = alpha * alpha * (zperm[i] - 1) % r * pow(n * (x - 1) % r, -1, r) % r
+        # Plookup part
+        vanish = (pow(x, n, r) - 1) % r
+        l1 = vanish * pow(n * (x - 1) % r, -1, r) % r
+        ln = vanish * wn_inv % r * pow(n * (x - wn_inv) % r, -1, r) % r
+        l1_div = l1 * pow(vanish, -1, r) % r
+        ln_div = ln * pow(vanish, -1, r) % r
+        mt = lambda rg, ky, ql, w3, w4, td: (rg + ql * tau * (td + tau * (ky + tau * (w3 + tau * w4)))) % r
+        mt_x = mt(rng_t[i], key_t[i], q_lookup[i], w[3], w[4], tds[i])
+        mt_xw = mt(rng_t[nx], key_t[nx], q_lookup[nx], wn[3], wn[4], tds[nx])
+        ml_x = (w[5] + q_lookup[i] * tau * (qds[i] + tau * (w[0] + tau * (w[1] + tau * w[2])))) % r
+        ap = pow(alpha, 3, r)
+        res2 = ap * (h1[i] - h2[nx]) % r * ln_div % r
+        ap = ap * alpha % r
+        res2 += ap * (pl[i] - 1) % r * l1_div % r
+        ap = ap * alpha % r
+        res2 += ap * (pl[i] - 1) % r * ln_div % r
+        ap = ap * alpha % r
+        b1 = (1 + beta) % r
+        gb = b1 * gamma % r
+        p3 = (x - wn_inv) * (pl[i] * b1 % r * (gamma + ml_x) % r * (gb + mt_x + beta * mt_xw) % r
+                             - pl[nx] * (gb + h1[i] + beta * h1[nx]) % r * (gb + h2[i] + beta * h2[nx])) % r
+        res1 = ap * p3 % r
+        t = ((t_circ + t_perm_1 + res1) * zh_inv[i % ratio] + t_perm_2 + res2) % r
+        out.append(alpha_base * t % r)
+    return out

@@ -92,6 +92,98 @@ def test_quotient_of_satisfied_circuit_is_a_low_degree_polynomial(cv):
     assert from_mont_arr(cv.fr, got) == t
 
 
+def random_ultra_instance(cv, log_n, log_m, seed):
+    m = 1 << log_m
+    f = lambda polys, s: rand_fr_mont(cv, polys * m, seed + s).reshape(polys, m, 4)
+    return dict(sel=f(14, 1), sig=f(6, 2), wires=f(6, 3), zperm=f(1, 4)[0], pi=f(1, 5)[0], lookup=f(7, 8),
+                k=rand_fr_mont(cv, 6, seed + 6), ch=rand_fr_mont(cv, 5, seed + 7))  # alpha beta gamma tau alpha_base
+
+
+@pytest.mark.parametrize("cv", CURVES, ids=lambda c: c.name)
+def test_ultra_quotient_c_matches_bigint(cv):
+    """prover.rs:766-882 (Plookup part) on top of the 6-wire gate / copy-constraint parts"""
+    log_n, log_m = 2, 5
+    inst = random_ultra_instance(cv, log_n, log_m, 300)
+    ints = lambda a: [from_mont_arr(cv.fr, p) for p in a]
+    ch = from_mont_arr(cv.fr, inst["ch"])
+    exp = R.quotient_evals_ultra(cv, log_n, log_m, ints(inst["sel"]), ints(inst["sig"]), ints(inst["wires"]),
+                                 from_mont_arr(cv.fr, inst["zperm"]), from_mont_arr(cv.fr, inst["pi"]),
+                                 ints(inst["lookup"]), from_mont_arr(cv.fr, inst["k"]), ch[0], ch[1], ch[2], ch[3], ch[4])
+    got = C.plonk_quotient_ultra(cv.curve_id, log_n, log_m, inst["sel"], inst["sig"], inst["wires"], inst["zperm"],
+                                 inst["pi"], inst["lookup"], inst["k"], *inst["ch"])
+    assert from_mont_arr(cv.fr, got) == exp
+
+
+def satisfied_ultra_instance(cv, log_n, log_m, seed):
+    """A satisfied UltraPlonk instance in the reference's own shape (relation/src/constraint_system.rs:
+    1495-1624): gates as in satisfied_instance with a 6th (range) wire, identity permutation, and a
+    Plookup argument over a range table {0..n-2}: every lookup wire value is a table element,
+    q_lookup = 0 (pure range lookups), h1/h2 = halves of the sorted merged vector, prod_lookup = the
+    running product of compute_lookup_prod_vector."""
+    r = cv.fr.p
+    n = 1 << log_n
+    rng = R.SplitMix64(seed)
+    w = [[rng.field(cv.fr) for _ in range(n)] for _ in range(5)]
+    w.append([rng.next() % n for _ in range(n)])  # range wire: looked-up values (reduced into the table below)
+    sel = [[rng.field(cv.fr) for _ in range(n)] for _ in range(13)] + [[0] * n]
+    for i in range(n):
+        wi = [w[j][i] for j in range(5)]
+        rest = (sum(sel[j][i] * wi[j] for j in range(4)) + sel[4][i] * wi[0] * wi[1] + sel[5][i] * wi[2] * wi[3]
+                + sel[12][i] * wi[0] * wi[1] * wi[2] * wi[3] * wi[4]
+                + sum(sel[6 + j][i] * pow(wi[j], 5, r) for j in range(4)) - sel[10][i] * wi[4])
+        sel[11][i] = (-rest) % r
+    k = [1] + [rng.field(cv.fr) for _ in range(5)]
+    return w, sel, k
+
+
+@pytest.mark.parametrize("cv", CURVES, ids=lambda c: c.name)
+def test_ultra_quotient_of_satisfied_circuit_is_a_low_degree_polynomial(cv):
+    log_n, log_m = 3, 6
+    n, m = 1 << log_n, 1 << log_m
+    r = cv.fr.p
+    w, sel, k = satisfied_ultra_instance(cv, log_n, log_m, 11)
+    rng = R.SplitMix64(5)
+    alpha, beta, gamma, tau = (rng.field(cv.fr) for _ in range(4))
+    g = cv.fr_generator
+    coset = lambda evals_on_h: R.fft(cv, R.ifft(cv, evals_on_h, log_n), log_m, g)
+    wn = R.domain_root(cv, log_n)
+    xs = [pow(wn, i, r) for i in range(n)]
+    # Plookup vectors on H exactly as the reference builds them (relation/src/constraint_system.rs):
+    # compute_range_table :1630-1645, compute_lookup_sorted_vec_polynomials :1577-1624,
+    # compute_lookup_prod_polynomial :1516-1575.  q_lookup = 0, so merged table = range table and the
+    # merged lookup witness = the range wire.
+    range_size = n // 2
+    table = list(range(range_size)) + [0] * (n - range_size)
+    w[5] = [v % range_size for v in w[5]]
+    lookups = w[5][: n - 1]
+    cnt = {}
+    for v in lookups:
+        cnt[v] = cnt.get(v, 0) + 1
+    srt = []
+    for v in table:
+        if v in cnt:
+            srt += [v] * (1 + cnt.pop(v))
+        else:
+            srt.append(v)
+    assert len(srt) == 2 * n - 1
+    h1, h2 = srt[:n], srt[n - 1:]
+    b1 = (1 + beta) % r
+    gb = gamma * b1 % r
+    prod = [1]
+    for j in range(n - 2):
+        num = b1 * (gamma + lookups[j]) % r * (gb + table[j] + beta * table[j + 1]) % r
+        den = (gb + srt[j] + beta * srt[j + 1]) % r * (gb + srt[n - 1 + j] + beta * srt[n + j]) % r
+        prod.append(prod[-1] * num % r * pow(den, -1, r) % r)
+    prod.append(1)
+    zero = [0] * n
+    lookup = [coset(table), coset(zero), coset(zero), coset(zero), coset(h1), coset(h2), coset(prod)]
+    sig = [coset([k[j] * x % r for x in xs]) for j in range(6)]
+    t = R.quotient_evals_ultra(cv, log_n, log_m, [coset(s) for s in sel], sig, [coset(x) for x in w], coset([1] * n),
+                               coset(zero), lookup, k, alpha, beta, gamma, tau)
+    coeffs = R.ifft(cv, t, log_m, g)
+    assert any(coeffs[: 6 * n]) and not any(coeffs[6 * n:])
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("cv", CURVES, ids=lambda c: c.name)
 @pytest.mark.parametrize("log_n,log_m", [(2, 5), (6, 9), (10, 13), (13, 16)])
@@ -114,5 +206,30 @@ def test_quotient_gpu_matches_oracle(hip, cv, log_n, log_m):
                                   inst["pi"], inst["k"], *inst["ch"])
     exp = C.plonk_quotient_turbo(cv.curve_id, log_n, log_m, inst["sel"], inst["sig"], inst["wires"], inst["zperm"],
                                  inst["pi"], inst["k"], *inst["ch"], out=once)
+    assert (got == exp).all()
+    st.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cv", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("log_n,log_m", [(2, 5), (6, 9), (11, 14)])
+def test_ultra_quotient_gpu_matches_oracle(hip, cv, log_n, log_m):
+    import torch
+
+    inst = random_ultra_instance(cv, log_n, log_m, 900 + log_n)
+    m = 1 << log_m
+    dev = {k: torch.from_numpy(np.ascontiguousarray(inst[k]).view(np.int64)).cuda()
+           for k in ("sel", "sig", "wires", "zperm", "pi", "lookup")}
+    quot = torch.zeros(m * 4, dtype=torch.int64, device="cuda")
+    st = hip.Stream()
+    for rep in range(2):
+        hip.plonk_quotient_ultra_device(cv.curve_id, log_n, log_m, dev["sel"].data_ptr(), dev["sig"].data_ptr(),
+                                        dev["wires"].data_ptr(), dev["zperm"].data_ptr(), dev["pi"].data_ptr(),
+                                        dev["lookup"].data_ptr(), inst["k"], inst["ch"], quot.data_ptr(), stream=st)
+    st.sync()
+    got = quot.cpu().numpy().view(np.uint64).reshape(m, 4)
+    args = (cv.curve_id, log_n, log_m, inst["sel"], inst["sig"], inst["wires"], inst["zperm"], inst["pi"],
+            inst["lookup"], inst["k"], *inst["ch"])
+    exp = C.plonk_quotient_ultra(*args, out=C.plonk_quotient_ultra(*args))
     assert (got == exp).all()
     st.close()
