@@ -23,8 +23,8 @@ import torch.distributed as dist
 class MsmEngine(Protocol):
     partial_bytes: int
 
-    def partial(self, scalars: torch.Tensor) -> torch.Tensor:
-        """this rank's partial sum over its resident point range -> uint8[partial_bytes]"""
+    def partial(self, scalars: torch.Tensor, offset: int = 0) -> torch.Tensor:
+        """partial sum of scalars[i] * P[offset + i] over this rank's resident points -> uint8[partial_bytes]"""
 
     def fold(self, partials: torch.Tensor, count: int) -> torch.Tensor:
         """sum `count` gathered partials and normalise -> uint8 packed affine + 4-byte flag"""
@@ -42,16 +42,29 @@ class HipMsmEngine:
         self.stream = stream or lib.Stream(wrap_raw=torch.cuda.current_stream().cuda_stream)
         self._out = torch.zeros(2 * self.fq_bytes + 16, dtype=torch.uint8, device="cuda")
 
-    def partial(self, scalars: torch.Tensor) -> torch.Tensor:
+    def partial(self, scalars: torch.Tensor, offset: int = 0) -> torch.Tensor:
         assert scalars.is_cuda and scalars.is_contiguous()
         n = scalars.numel() * scalars.element_size() // 32
         out = torch.empty(self.partial_bytes, dtype=torch.uint8, device="cuda")
-        self.lib.msm_partial_device(self.srs, scalars.data_ptr(), n, out.data_ptr(), stream=self.stream)
+        self.lib.msm_partial_device(self.srs, scalars.data_ptr(), n, out.data_ptr(), offset=offset, stream=self.stream)
         return out
 
     def fold(self, partials: torch.Tensor, count: int) -> torch.Tensor:
         self.lib.g1_sum_partials(self.curve, partials.data_ptr(), count, self._out.data_ptr(), stream=self.stream)
         return self._out[: 2 * self.fq_bytes + 4]
+
+
+def _all_gather_bytes(mine: torch.Tensor, world: int, group=None) -> torch.Tensor:
+    """all_gather of a small uint8 tensor.  RCCL ("nccl") gathers device tensors in place; the gloo
+    backend (CPU tests, single-GPU rehearsals) is given host tensors."""
+    if mine.is_cuda and dist.get_backend(group) == "gloo":
+        host = mine.cpu()
+        out = torch.empty(world * host.numel(), dtype=torch.uint8)
+        dist.all_gather_into_tensor(out, host, group=group)
+        return out.to(mine.device)
+    out = torch.empty(world * mine.numel(), dtype=torch.uint8, device=mine.device)
+    dist.all_gather_into_tensor(out, mine, group=group)
+    return out
 
 
 def shard_range(n: int, rank: int, world: int) -> tuple[int, int]:
@@ -71,9 +84,31 @@ def sharded_msm(engine: MsmEngine, local_scalars: torch.Tensor, group=None) -> t
     part = engine.partial(local_scalars)
     if world == 1:
         return engine.fold(part, 1)
-    gathered = torch.empty(world * engine.partial_bytes, dtype=torch.uint8, device=part.device)
-    dist.all_gather_into_tensor(gathered, part, group=group)
-    return engine.fold(gathered, world)
+    return engine.fold(_all_gather_bytes(part, world, group), world)
+
+
+def sharded_commit_batch(engine: MsmEngine, polys: Sequence[torch.Tensor], group=None) -> list:
+    """P commitments (batch_commit, reference pcs/src/univariate_kzg/mod.rs:128-140) against an SRS that is
+    REPLICATED on every rank: rank k takes the coefficient range shard_range(len, k, G) of every
+    polynomial (so every GPU does 1/G of every MSM), and ONE all_gather carries the P partial sums of
+    all ranks (P x 128 B per rank for BN254).  polys: flat int64 coefficient tensors (4 words per
+    coefficient), identical on all ranks.  Returns P packed affine results (uint8 tensors)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    P = len(polys)
+    if P == 0:
+        return []
+    parts = []
+    for poly in polys:
+        n = poly.numel() // 4
+        lo, hi = shard_range(n, rank, world)
+        parts.append(engine.partial(poly[4 * lo:4 * hi], offset=lo))
+    mine = torch.cat(parts)
+    if world == 1:
+        return [engine.fold(parts[j], 1).clone() for j in range(P)]
+    gathered = _all_gather_bytes(mine, world, group)
+    per_poly = gathered.view(world, P, engine.partial_bytes).transpose(0, 1).contiguous()
+    return [engine.fold(per_poly[j].reshape(-1), world).clone() for j in range(P)]
 
 
 def round_robin(items: Sequence, rank: int, world: int) -> list:

@@ -45,15 +45,26 @@ def _dev(a: np.ndarray) -> torch.Tensor:
 class TurboPlonkHotPath:
     """One TurboPlonk instance of n gates on the current device (curve: L.BN254 / L.BLS12_381)."""
 
-    def __init__(self, curve: int, log_n: int, srs: "L.Srs", rand_fr, stream: "L.Stream | None" = None):
-        """rand_fr(count, seed) -> (count, 4) uint64 Montgomery field elements (synthetic inputs)"""
+    def __init__(self, curve: int, log_n: int, srs: "L.Srs", rand_fr, stream: "L.Stream | None" = None,
+                 sharded: bool = False, group=None):
+        """rand_fr(count, seed) -> (count, 4) uint64 Montgomery field elements (synthetic inputs).
+        sharded: torch.distributed is initialised, `srs` is replicated on every rank, and every
+        commitment's coefficient range is partitioned over the ranks (BASELINE config 4: "MSM point
+        ranges sharded across 8 MI355X"); one all_gather of partial sums per commit round.  The
+        transforms and the quotient are computed redundantly on every rank in this mode."""
         self.curve, self.log_n = curve, log_n
+        self.sharded, self.group = sharded, group
         self.n = n = 1 << log_n
         self.m = m = quot_domain_size(n, NUM_WIRE_TYPES)
         self.log_m = m.bit_length() - 1
         self.srs = srs
         assert len(srs) >= n + 3, "SRS must cover degree n + 2"
         self.stream = stream or L.Stream(wrap_raw=torch.cuda.current_stream().cuda_stream)
+        if sharded:
+            from . import dist as jdist
+
+            self._jdist = jdist
+            self._engine = jdist.HipMsmEngine(L, srs, self.stream)
         self.fq_bytes = 8 * L.FQ_LIMBS64[curve]
         self.gen = L.field_op(0 if curve == L.BN254 else 2, "to_mont",
                               np.array([5 if curve == L.BN254 else 7, 0, 0, 0], dtype=np.uint64))
@@ -90,8 +101,19 @@ class TurboPlonkHotPath:
         self.evals = torch.zeros(10 * 4, dtype=torch.int64, device="cuda")
 
     # ---- helpers ------------------------------------------------------------------------------
-    def _commit(self, slot: int, ptr: int, length: int):
-        L.msm_device(self.srs, ptr, length, self.commits.data_ptr() + slot * self.rec, stream=self.stream)
+    def _commit_many(self, slot: int, polys):
+        """batch_commit of coefficient tensors (int64, 4 words per coefficient) into commitment slots"""
+        if not self.sharded:
+            if len(polys) == 1:
+                L.msm_device(self.srs, polys[0].data_ptr(), polys[0].numel() // 4,
+                             self.commits.data_ptr() + slot * self.rec, stream=self.stream)
+            else:
+                L.msm_batch_device(self.srs, [p.data_ptr() for p in polys], [p.numel() // 4 for p in polys],
+                                   self.commits.data_ptr() + slot * self.rec, stream=self.stream)
+            return
+        outs = self._jdist.sharded_commit_batch(self._engine, polys, group=self.group)
+        for j, o in enumerate(outs):
+            self.commits[(slot + j) * self.rec:(slot + j) * self.rec + o.numel()] = o
 
     def _blind(self, poly: torch.Tensor, count: int, which: int):
         """mask_polynomial (prover.rs:457-466) adds (b0 + b1 X ..)(X^n - 1): `count` extra top
@@ -114,13 +136,12 @@ class TurboPlonkHotPath:
         for j in range(W):
             self._blind(self.wire_polys[j], 2, j)
         self.pub_poly[:n4].copy_(self.ntt_buf[W])
-        L.msm_batch_device(self.srs, [self.wire_polys[j].data_ptr() for j in range(W)], [n + 2] * W,
-                           self.commits.data_ptr(), stream=st)
+        self._commit_many(0, [self.wire_polys[j][:(n + 2) * 4] for j in range(W)])
         # Round 2 (prover.rs:128-142): permutation product polynomial (values are an input), commit
         L.ntt_device(c, self.ntt_buf[W + 1].data_ptr(), self.log_n, 1, inverse=True, stream=st)
         self.perm_poly[:n4].copy_(self.ntt_buf[W + 1])
         self._blind(self.perm_poly, 3, W)
-        self._commit(5, self.perm_poly.data_ptr(), n + 3)
+        self._commit_many(5, [self.perm_poly[:(n + 3) * 4]])
         # Round 3 (prover.rs:183-198, 491-661): coset NTTs (zero extension on device), quotient, split, commit
         ln4 = (n + 3) * 4
         cs = self.coset
@@ -139,8 +160,7 @@ class TurboPlonkHotPath:
                                       stream=st)
         L.ntt_device(c, self.quot.data_ptr(), self.log_m, 1, inverse=True, coset_mont=self.gen, stream=st)
         # split_quotient_polynomial (prover.rs:894-943): W chunks of n + 2 coefficients
-        L.msm_batch_device(self.srs, [self.quot.data_ptr() + j * (n + 2) * 32 for j in range(W)], [n + 2] * W,
-                           self.commits.data_ptr() + 6 * self.rec, stream=st)
+        self._commit_many(6, [self.quot[j * (n + 2) * 4:(j + 1) * (n + 2) * 4] for j in range(W)])
         # Round 4 (prover.rs:205-229): evaluations of wires (5), sigmas (4) at zeta and z at zeta*omega
         L.poly_eval_batch_device(c, [self.wire_polys[j].data_ptr() for j in range(W)]
                                  + [self.sigmas[j].data_ptr() for j in range(W - 1)], [n + 2] * W + [n] * (W - 1),
@@ -162,8 +182,8 @@ class TurboPlonkHotPath:
         lens += [n] * (W - 1)
         L.poly_lincomb_device(c, ptrs, lens, self.lin_coeffs[:len(ptrs)], self.open_poly.data_ptr(), n + 3, stream=st)
         L.poly_divide_linear_device(c, self.open_poly.data_ptr(), n + 3, self.zeta, self.scratch.data_ptr(), stream=st)
-        self._commit(11, self.scratch.data_ptr() + 32, n + 2)
+        self._commit_many(11, [self.scratch[4:4 + (n + 2) * 4]])
         L.poly_divide_linear_device(c, self.perm_poly.data_ptr(), n + 3, self.zeta_omega, self.scratch.data_ptr(),
                                     stream=st)
-        self._commit(12, self.scratch.data_ptr() + 32, n + 2)
+        self._commit_many(12, [self.scratch[4:4 + (n + 2) * 4]])
         return self.commits

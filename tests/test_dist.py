@@ -30,9 +30,9 @@ class OracleEngine:
         self.C, self.curve, self.bases = C, curve, bases
         self.partial_bytes = bases.shape[1] * 8
 
-    def partial(self, scalars):
+    def partial(self, scalars, offset=0):
         sc = scalars.numpy().view(np.uint64).reshape(-1, 4)
-        out = self.C.msm(self.curve, self.bases, sc, threads=2)
+        out = self.C.msm(self.curve, self.bases[offset:offset + len(sc)], sc, threads=2)
         return torch.from_numpy(out.view(np.uint8).copy())
 
     def fold(self, partials, count):
@@ -61,6 +61,13 @@ def _worker(rank, world, port, n, q):
     res = jdist.sharded_msm(eng, torch.from_numpy(sc[lo:hi].view(np.int64).copy()))
     full = C.msm(0, srs, sc, threads=2)
     ok = bool((res.numpy()[:64].view(np.uint64) == full).all()) and res.numpy()[64:68].view(np.uint32)[0] == 0
+    # batch_commit with coefficient ranges sharded over the ranks (replicated SRS, ragged lengths)
+    full_eng = OracleEngine(0, srs)
+    lens = [n, n - 3, 5, 1]
+    polys = [torch.from_numpy(sc[:l].view(np.int64).reshape(-1).copy()) for l in lens]
+    outs = jdist.sharded_commit_batch(full_eng, polys)
+    for l, o in zip(lens, outs):
+        ok = ok and bool((o.numpy()[:64].view(np.uint64) == C.msm(0, srs[:l], sc[:l], threads=2)).all())
     # round-robin of independent units covers everything exactly once
     mine = jdist.round_robin(list(range(11)), rank, world)
     gathered = [None] * world

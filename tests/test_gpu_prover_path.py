@@ -83,3 +83,21 @@ def test_prover_path_matches_oracle(hip, cv):
     q2, _ = C.open_witness(cid, perm_poly, rand(1, 20)[0])
     assert (got[12] == C.msm(cid, srs_host[:n + 2], q2)).all()
     srs.free()
+
+
+@pytest.mark.gpu
+def test_sharded_commit_mode_matches_single_device(hip):
+    """world size 1: the sharded-commit code path (partials -> fold) gives the same 13 commitments"""
+    from jellyfish_amd import prover_path as P
+
+    cv = R.BN254
+    log_n = 8
+    n = 1 << log_n
+    beta = mont_arr(cv.fr, [24680])[0]
+    srs = hip.Srs.gen_for_testing(0, beta, pt_arr(cv, cv.g), n + 8)
+    rand = lambda count, seed: rand_fr_mont(cv, count, 4000 + seed)
+    a = P.TurboPlonkHotPath(0, log_n, srs, rand).prove().cpu().numpy().copy()
+    b = P.TurboPlonkHotPath(0, log_n, srs, rand, sharded=True).prove().cpu().numpy().copy()
+    rec = a.size // 13
+    for j in range(13):
+        assert (a[j * rec:j * rec + 68] == b[j * rec:j * rec + 68]).all(), j
