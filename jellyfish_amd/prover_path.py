@@ -42,20 +42,27 @@ def _dev(a: np.ndarray) -> torch.Tensor:
     return torch.from_numpy(np.ascontiguousarray(a).view(np.int64).reshape(-1)).cuda()
 
 
-class TurboPlonkHotPath:
-    """One TurboPlonk instance of n gates on the current device (curve: L.BN254 / L.BLS12_381)."""
+class PlonkHotPath:
+    """One PLONK instance of n gates on the current device (curve: L.BN254 / L.BLS12_381).
+
+    ultra = False: TurboPlonk, 5 wire types, 13 selectors: 13 commitments.
+    ultra = True:  UltraPlonk with Plookup, 6 wire types, 14 selectors, 4 table polynomials in the
+    proving key and the online oracles h_1, h_2, prod_lookup (rounds 1.5 / 2.5, prover.rs:99-178):
+    11 iNTTs of size n, 35 coset NTTs of size 8n, 18 commitments."""
 
     def __init__(self, curve: int, log_n: int, srs: "L.Srs", rand_fr, stream: "L.Stream | None" = None,
-                 sharded: bool = False, group=None):
+                 sharded: bool = False, group=None, ultra: bool = False):
         """rand_fr(count, seed) -> (count, 4) uint64 Montgomery field elements (synthetic inputs).
         sharded: torch.distributed is initialised, `srs` is replicated on every rank, and every
         commitment's coefficient range is partitioned over the ranks (BASELINE config 4: "MSM point
         ranges sharded across 8 MI355X"); one all_gather of partial sums per commit round.  The
         transforms and the quotient are computed redundantly on every rank in this mode."""
-        self.curve, self.log_n = curve, log_n
+        self.curve, self.log_n, self.ultra = curve, log_n, ultra
         self.sharded, self.group = sharded, group
+        self.W = W = 6 if ultra else NUM_WIRE_TYPES
+        self.NSEL = NSEL = 14 if ultra else NUM_SELECTORS
         self.n = n = 1 << log_n
-        self.m = m = quot_domain_size(n, NUM_WIRE_TYPES)
+        self.m = m = quot_domain_size(n, W)
         self.log_m = m.bit_length() - 1
         self.srs = srs
         assert len(srs) >= n + 3, "SRS must cover degree n + 2"
@@ -69,27 +76,37 @@ class TurboPlonkHotPath:
         self.gen = L.field_op(0 if curve == L.BN254 else 2, "to_mont",
                               np.array([5 if curve == L.BN254 else 7, 0, 0, 0], dtype=np.uint64))
         # proving key, coefficient form, resident (preprocess(), snark.rs:492-580)
-        self.selectors = _dev(rand_fr(NUM_SELECTORS * n, 11)).view(NUM_SELECTORS, n * 4)
-        self.sigmas = _dev(rand_fr(NUM_WIRE_TYPES * n, 12)).view(NUM_WIRE_TYPES, n * 4)
-        self.k = rand_fr(NUM_WIRE_TYPES, 13)
+        self.selectors = _dev(rand_fr(NSEL * n, 11)).view(NSEL, n * 4)
+        self.sigmas = _dev(rand_fr(W * n, 12)).view(W, n * 4)
+        self.k = rand_fr(W, 13)
         # witness-dependent inputs: wire values, permutation-product values, public input values on H
-        self.wire_vals = _dev(rand_fr(NUM_WIRE_TYPES * n, 14)).view(NUM_WIRE_TYPES, n * 4)
+        self.wire_vals = _dev(rand_fr(W * n, 14)).view(W, n * 4)
         self.perm_vals = _dev(rand_fr(n, 15))
         self.pub_vals = _dev(rand_fr(n, 16))
         # host-side randomness and transcript outputs, fixed for the synthetic run
         self.blind = _dev(rand_fr(64, 17))
-        self.ch = rand_fr(4, 18)           # alpha, beta, gamma, alpha_base
+        self.ch = rand_fr(5 if ultra else 4, 18)   # alpha, beta, gamma, [tau,] alpha_base
         self.zeta = rand_fr(1, 19)[0]
         self.zeta_omega = rand_fr(1, 20)[0]
         self.lin_coeffs = rand_fr(32, 21)
+        if ultra:
+            # plookup_pk: range_table, key_table, table_dom_sep, q_dom_sep polynomials (snark.rs:508-521)
+            self.table_polys = _dev(rand_fr(4 * n, 22)).view(4, n * 4)
+            # values on H of the sorted-vector halves h_1, h_2 and of the lookup grand product (host-built in the
+            # reference: relation/src/constraint_system.rs:1516-1624; inputs here)
+            self.h_vals = _dev(rand_fr(2 * n, 23)).view(2, n * 4)
+            self.plprod_vals = _dev(rand_fr(n, 24))
         # working storage
         ln = n + 4                          # room for the n+2 / n+3 coefficients of a blinded polynomial
         self.ln = ln
-        self.wire_polys = torch.zeros(NUM_WIRE_TYPES, ln * 4, dtype=torch.int64, device="cuda")
+        self.wire_polys = torch.zeros(W, ln * 4, dtype=torch.int64, device="cuda")
         self.perm_poly = torch.zeros(ln * 4, dtype=torch.int64, device="cuda")
         self.pub_poly = torch.zeros(ln * 4, dtype=torch.int64, device="cuda")
-        self.ntt_buf = torch.zeros(NUM_WIRE_TYPES + 2, n * 4, dtype=torch.int64, device="cuda")
-        self.npolys = NUM_SELECTORS + 2 * NUM_WIRE_TYPES + 2
+        self.ntt_buf = torch.zeros(W + 2, n * 4, dtype=torch.int64, device="cuda")
+        self.npolys = NSEL + 2 * W + 2 + (7 if ultra else 0)
+        if ultra:
+            self.h_polys = torch.zeros(2, ln * 4, dtype=torch.int64, device="cuda")
+            self.plprod_poly = torch.zeros(ln * 4, dtype=torch.int64, device="cuda")
         self.coset = torch.zeros(self.npolys, m * 4, dtype=torch.int64, device="cuda")
         self.quot = torch.zeros(m * 4, dtype=torch.int64, device="cuda")
         self.lin_poly = torch.zeros(ln * 4, dtype=torch.int64, device="cuda")
@@ -97,8 +114,10 @@ class TurboPlonkHotPath:
         self.scratch = torch.zeros(ln * 4, dtype=torch.int64, device="cuda")
         rec = (2 * self.fq_bytes + 4 + 15) // 16 * 16
         self.rec = rec
-        self.commits = torch.zeros(13 * rec, dtype=torch.uint8, device="cuda")
-        self.evals = torch.zeros(10 * 4, dtype=torch.int64, device="cuda")
+        self.ncommit = 18 if ultra else 13
+        self.commits = torch.zeros(self.ncommit * rec, dtype=torch.uint8, device="cuda")
+        self.nevals = 27 if ultra else 10
+        self.evals = torch.zeros(self.nevals * 4, dtype=torch.int64, device="cuda")
 
     # ---- helpers ------------------------------------------------------------------------------
     def _commit_many(self, slot: int, polys):
@@ -126,7 +145,8 @@ class TurboPlonkHotPath:
     def prove(self) -> torch.Tensor:
         c, n, m, st = self.curve, self.n, self.m, self.stream
         n4 = n * 4
-        W = NUM_WIRE_TYPES
+        W, NSEL, ultra = self.W, self.NSEL, self.ultra
+        slot = 0
         # Round 1 (prover.rs:77-91): wire polynomials = iNTT of wire values, blind, commit; pub input poly
         self.ntt_buf[:W].copy_(self.wire_vals)
         self.ntt_buf[W].copy_(self.pub_vals)
@@ -136,54 +156,113 @@ class TurboPlonkHotPath:
         for j in range(W):
             self._blind(self.wire_polys[j], 2, j)
         self.pub_poly[:n4].copy_(self.ntt_buf[W])
-        self._commit_many(0, [self.wire_polys[j][:(n + 2) * 4] for j in range(W)])
+        self._commit_many(slot, [self.wire_polys[j][:(n + 2) * 4] for j in range(W)])
+        slot += W
+        if ultra:
+            # Round 1.5 (prover.rs:99-124): h_1, h_2 = iNTT of the sorted-vector halves, blind (bound 2), commit
+            self.ntt_buf[:2].copy_(self.h_vals)
+            L.ntt_device(c, self.ntt_buf.data_ptr(), self.log_n, 2, inverse=True, stream=st)
+            self.h_polys[:, :n4].copy_(self.ntt_buf[:2])
+            for j in range(2):
+                self._blind(self.h_polys[j], 3, 6 + 2 * j)
+            self._commit_many(slot, [self.h_polys[j][:(n + 3) * 4] for j in range(2)])
+            slot += 2
         # Round 2 (prover.rs:128-142): permutation product polynomial (values are an input), commit
         L.ntt_device(c, self.ntt_buf[W + 1].data_ptr(), self.log_n, 1, inverse=True, stream=st)
         self.perm_poly[:n4].copy_(self.ntt_buf[W + 1])
-        self._blind(self.perm_poly, 3, W)
-        self._commit_many(5, [self.perm_poly[:(n + 3) * 4]])
+        self._blind(self.perm_poly, 3, 10 if ultra else W)
+        self._commit_many(slot, [self.perm_poly[:(n + 3) * 4]])
+        slot += 1
+        if ultra:
+            # Round 2.5 (prover.rs:147-178): lookup grand-product polynomial, blind (bound 2), commit
+            self.ntt_buf[0].copy_(self.plprod_vals)
+            L.ntt_device(c, self.ntt_buf.data_ptr(), self.log_n, 1, inverse=True, stream=st)
+            self.plprod_poly[:n4].copy_(self.ntt_buf[0])
+            self._blind(self.plprod_poly, 3, 12)
+            self._commit_many(slot, [self.plprod_poly[:(n + 3) * 4]])
+            slot += 1
         # Round 3 (prover.rs:183-198, 491-661): coset NTTs (zero extension on device), quotient, split, commit
         ln4 = (n + 3) * 4
         cs = self.coset
-        cs[:NUM_SELECTORS, :n4].copy_(self.selectors)
-        cs[NUM_SELECTORS:NUM_SELECTORS + W, :n4].copy_(self.sigmas)
-        cs[:NUM_SELECTORS + W, n4:ln4].zero_()
-        cs[NUM_SELECTORS + W:NUM_SELECTORS + 2 * W, :ln4].copy_(self.wire_polys[:, :ln4])
-        cs[NUM_SELECTORS + 2 * W, :ln4].copy_(self.perm_poly[:ln4])
-        cs[NUM_SELECTORS + 2 * W + 1, :ln4].copy_(self.pub_poly[:ln4])
+        o_sig, o_w, o_z, o_pi, o_lk = NSEL, NSEL + W, NSEL + 2 * W, NSEL + 2 * W + 1, NSEL + 2 * W + 2
+        cs[:NSEL, :n4].copy_(self.selectors)
+        cs[o_sig:o_w, :n4].copy_(self.sigmas)
+        cs[:o_w, n4:ln4].zero_()
+        cs[o_w:o_z, :ln4].copy_(self.wire_polys[:, :ln4])
+        cs[o_z, :ln4].copy_(self.perm_poly[:ln4])
+        cs[o_pi, :ln4].copy_(self.pub_poly[:ln4])
+        if ultra:
+            # prover.rs:559-573; stored in the quotient kernel's order range, key, table_dom_sep, q_dom_sep, h1, h2, prod
+            cs[o_lk:o_lk + 4, :n4].copy_(self.table_polys)
+            cs[o_lk:o_lk + 4, n4:ln4].zero_()
+            cs[o_lk + 4:o_lk + 6, :ln4].copy_(self.h_polys[:, :ln4])
+            cs[o_lk + 6, :ln4].copy_(self.plprod_poly[:ln4])
         L.ntt_device(c, cs.data_ptr(), self.log_m, self.npolys, inverse=False, coset_mont=self.gen, in_len=n + 3,
                      stream=st)
         self.quot.zero_()
-        L.plonk_quotient_turbo_device(c, self.log_n, self.log_m, cs[0].data_ptr(), cs[NUM_SELECTORS].data_ptr(),
-                                      cs[NUM_SELECTORS + W].data_ptr(), cs[NUM_SELECTORS + 2 * W].data_ptr(),
-                                      cs[NUM_SELECTORS + 2 * W + 1].data_ptr(), self.k, self.ch, self.quot.data_ptr(),
-                                      stream=st)
+        if ultra:
+            L.plonk_quotient_ultra_device(c, self.log_n, self.log_m, cs[0].data_ptr(), cs[o_sig].data_ptr(),
+                                          cs[o_w].data_ptr(), cs[o_z].data_ptr(), cs[o_pi].data_ptr(),
+                                          cs[o_lk].data_ptr(), self.k, self.ch, self.quot.data_ptr(), stream=st)
+        else:
+            L.plonk_quotient_turbo_device(c, self.log_n, self.log_m, cs[0].data_ptr(), cs[o_sig].data_ptr(),
+                                          cs[o_w].data_ptr(), cs[o_z].data_ptr(), cs[o_pi].data_ptr(), self.k, self.ch,
+                                          self.quot.data_ptr(), stream=st)
         L.ntt_device(c, self.quot.data_ptr(), self.log_m, 1, inverse=True, coset_mont=self.gen, stream=st)
         # split_quotient_polynomial (prover.rs:894-943): W chunks of n + 2 coefficients
-        self._commit_many(6, [self.quot[j * (n + 2) * 4:(j + 1) * (n + 2) * 4] for j in range(W)])
-        # Round 4 (prover.rs:205-229): evaluations of wires (5), sigmas (4) at zeta and z at zeta*omega
-        L.poly_eval_batch_device(c, [self.wire_polys[j].data_ptr() for j in range(W)]
-                                 + [self.sigmas[j].data_ptr() for j in range(W - 1)], [n + 2] * W + [n] * (W - 1),
-                                 self.zeta, self.evals.data_ptr(), stream=st)
-        L.poly_eval_batch_device(c, [self.perm_poly.data_ptr()], [n + 3], self.zeta_omega,
-                                 self.evals.data_ptr() + 9 * 32, stream=st)
-        # linearisation polynomial (prover.rs:299-352, 946-1087): 13 selectors, z, last sigma, 5 quotient chunks
+        chunks = [self.quot[j * (n + 2) * 4:(j + 1) * (n + 2) * 4] for j in range(W)]
+        self._commit_many(slot, chunks)
+        slot += W
+        # Round 4 (prover.rs:205-229): evaluations of wires, sigmas (all but the last) at zeta and z at zeta*omega
+        at_zeta = [(self.wire_polys[j], n + 2) for j in range(W)] + [(self.sigmas[j], n) for j in range(W - 1)]
+        at_zw = [(self.perm_poly, n + 3)]
+        if ultra:
+            # Round 4.5 (prover.rs:233-296)
+            rt, kt, tds, qds = (self.table_polys[j] for j in range(4))
+            ql = self.selectors[NSEL - 1]
+            at_zeta += [(rt, n), (kt, n), (self.h_polys[0], n + 3), (ql, n), (tds, n), (qds, n)]
+            at_zw += [(self.plprod_poly, n + 3), (rt, n), (kt, n), (self.h_polys[0], n + 3), (self.h_polys[1], n + 3),
+                      (ql, n), (self.wire_polys[3], n + 2), (self.wire_polys[4], n + 2), (tds, n)]
+        L.poly_eval_batch_device(c, [p.data_ptr() for p, _ in at_zeta], [l for _, l in at_zeta], self.zeta,
+                                 self.evals.data_ptr(), stream=st)
+        L.poly_eval_batch_device(c, [p.data_ptr() for p, _ in at_zw], [l for _, l in at_zw], self.zeta_omega,
+                                 self.evals.data_ptr() + len(at_zeta) * 32, stream=st)
+        # linearisation polynomial (prover.rs:299-352, 946-1087): 13 gate selectors, z, last sigma, quotient chunks
+        # (+ prod_lookup and h_2 for Plookup, prover.rs:1017-1087)
         ptrs = [self.selectors[j].data_ptr() for j in range(NUM_SELECTORS)]
         lens = [n] * NUM_SELECTORS
         ptrs += [self.perm_poly.data_ptr(), self.sigmas[W - 1].data_ptr()]
         lens += [n + 3, n]
-        ptrs += [self.quot.data_ptr() + j * (n + 2) * 32 for j in range(W)]
+        ptrs += [ch.data_ptr() for ch in chunks]
         lens += [n + 2] * W
+        if ultra:
+            ptrs += [self.plprod_poly.data_ptr(), self.h_polys[1].data_ptr()]
+            lens += [n + 3, n + 3]
         L.poly_lincomb_device(c, ptrs, lens, self.lin_coeffs[:len(ptrs)], self.lin_poly.data_ptr(), n + 3, stream=st)
         # Round 5 (prover.rs:356-413, 470-488): batched opening polynomial at zeta, divide, commit; same at zeta*omega
-        ptrs = [self.lin_poly.data_ptr()] + [self.wire_polys[j].data_ptr() for j in range(W)]
-        lens = [n + 3] + [n + 2] * W
-        ptrs += [self.sigmas[j].data_ptr() for j in range(W - 1)]
-        lens += [n] * (W - 1)
+        ptrs = [self.lin_poly.data_ptr()] + [p.data_ptr() for p, _ in at_zeta]
+        lens = [n + 3] + [l for _, l in at_zeta]
         L.poly_lincomb_device(c, ptrs, lens, self.lin_coeffs[:len(ptrs)], self.open_poly.data_ptr(), n + 3, stream=st)
         L.poly_divide_linear_device(c, self.open_poly.data_ptr(), n + 3, self.zeta, self.scratch.data_ptr(), stream=st)
-        self._commit_many(11, [self.scratch[4:4 + (n + 2) * 4]])
-        L.poly_divide_linear_device(c, self.perm_poly.data_ptr(), n + 3, self.zeta_omega, self.scratch.data_ptr(),
-                                    stream=st)
-        self._commit_many(12, [self.scratch[4:4 + (n + 2) * 4]])
+        self._commit_many(slot, [self.scratch[4:4 + (n + 2) * 4]])
+        slot += 1
+        if len(at_zw) == 1:
+            L.poly_divide_linear_device(c, self.perm_poly.data_ptr(), n + 3, self.zeta_omega, self.scratch.data_ptr(),
+                                        stream=st)
+        else:
+            L.poly_lincomb_device(c, [p.data_ptr() for p, _ in at_zw], [l for _, l in at_zw],
+                                  self.lin_coeffs[:len(at_zw)], self.open_poly.data_ptr(), n + 3, stream=st)
+            L.poly_divide_linear_device(c, self.open_poly.data_ptr(), n + 3, self.zeta_omega, self.scratch.data_ptr(),
+                                        stream=st)
+        self._commit_many(slot, [self.scratch[4:4 + (n + 2) * 4]])
         return self.commits
+
+
+class TurboPlonkHotPath(PlonkHotPath):
+    def __init__(self, curve, log_n, srs, rand_fr, stream=None, sharded=False, group=None):
+        super().__init__(curve, log_n, srs, rand_fr, stream, sharded, group, ultra=False)
+
+
+class UltraPlonkHotPath(PlonkHotPath):
+    def __init__(self, curve, log_n, srs, rand_fr, stream=None, sharded=False, group=None):
+        super().__init__(curve, log_n, srs, rand_fr, stream, sharded, group, ultra=True)
