@@ -112,6 +112,59 @@ def prove_section(L, torch, dist, world, stream, beta):
     return sec
 
 
+BLS_G = np.array([0x5cb38790fd530c16, 0x7817fc679976fff5, 0x154f95c7143ba1c1, 0xf0ae6acdf3d0e747, 0xedce6ecc21dbf440,
+                  0x120177419e0bfb75, 0xbaac93d50ce72271, 0x8c22631a7918fd8e, 0xdd595f13570725ce, 0x51ac582950405194,
+                  0x0e1c8c3fad0059c0, 0x0bbc3efc5008a26a], dtype=np.uint64)  # BLS12-381 G1 generator, Montgomery
+
+
+def batch_prove_section(L, torch, dist, world, rank, stream, log_g):
+    """BASELINE config 5 shape: batch_prove of `world` independent UltraPlonk (Plookup) circuits of 2^log_g gates on
+    BLS12-381, one circuit per GPU; the only exchange is one all_gather of 18 group elements per rank
+    (jellyfish_amd/dist.py batch_prove_one_per_rank).  Synthetic inputs are generated on the device."""
+    import hashlib
+
+    from jellyfish_amd import dist as jdist
+    from jellyfish_amd import prover_path as PP
+
+    def rand_dev(cnt, seed):
+        g = torch.Generator(device="cuda")
+        g.manual_seed(90000 + 1000 * rank + seed)
+        t = torch.randint(-(1 << 63), (1 << 63) - 1, (cnt, 4), dtype=torch.int64, device="cuda", generator=g)
+        t[:, 3] &= (1 << 60) - 1   # < 2^252 < r: valid Montgomery representatives
+        return t
+
+    beta = uniform_fr(1, 0x6A660005, BLS_R)[0]
+    srs_p = L.Srs.gen_for_testing(1, beta, BLS_G, (1 << log_g) + 8)
+    hp = PP.UltraPlonkHotPath(1, log_g, srs_p, rand_dev, stream)
+    jdist.batch_prove_one_per_rank(hp, L)
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(3):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = jdist.batch_prove_one_per_rank(hp, L)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        ts.append(dt * 1e3)
+    sec = {"workload": "batch_prove, %d UltraPlonk (Plookup) BLS12-381 circuits of 2^%d gates, one per GPU: per circuit "
+                       "11 iNTT(n) + 35 coset NTT(8n) + Plookup quotient + coset iNTT(8n) + 18 commitments + 27 evaluations"
+                       % (world, log_g),
+           "n_gpus": world, "ms": round(float(np.median(ts)), 3), "runs_ms": [round(t, 3) for t in ts],
+           "circuits_per_s": round(world / (float(np.median(ts)) * 1e-3), 3),
+           "excluded": "host transcript, RNG, grand products and sorted lookup vector (inputs here)",
+           "aggregated_sha": hashlib.sha256(bytes(res["aggregated"].cpu().numpy().tobytes())).hexdigest()[:16]}
+    srs_p.free()
+    del hp
+    torch.cuda.empty_cache()
+    return sec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -121,6 +174,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ntt", action="store_true")
     ap.add_argument("--no-prove", action="store_true")
+    ap.add_argument("--ultra-log-n", type=int, default=22,
+                    help="also run BASELINE config 5: batch_prove of UltraPlonk BLS12-381 circuits of 2^K gates, "
+                         "one circuit per GPU (config 5 is K = 22; 0 skips it)")
     args = ap.parse_args()
 
     import torch
@@ -301,6 +357,14 @@ def main():
             sec = {"error": repr(e)}
         if rank == 0:
             out["plonk_prove_hot_path"] = sec
+
+    if args.ultra_log_n:
+        try:
+            sec = batch_prove_section(L, torch, dist, world, rank, stream, args.ultra_log_n)
+        except Exception as e:
+            sec = {"error": repr(e)}
+        if rank == 0:
+            out["batch_prove_ultra"] = sec
 
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -114,3 +114,45 @@ def sharded_commit_batch(engine: MsmEngine, polys: Sequence[torch.Tensor], group
 def round_robin(items: Sequence, rank: int, world: int) -> list:
     """independent units (polynomials to transform / commit, circuits to prove): unit i -> rank i % world"""
     return [x for i, x in enumerate(items) if i % world == rank]
+
+
+def batch_prove_one_per_rank(hp, lib, group=None) -> dict:
+    """batch_prove with one circuit per GPU (BASELINE config 5; reference
+    plonk/src/proof_system/snark.rs:61-74 -> :163-430).
+
+    `hp` is this rank's PlonkHotPath instance (its own circuit; its alpha_base challenge already carries
+    the instance weight alpha^(3k) / alpha^(7k), prover.rs:644-655).  Every step of the aggregated proof
+    that mixes instances is LINEAR in the instances -- the quotient sum, its split chunks, the
+    linearisation polynomial and the two batched opening polynomials -- so each GPU commits its own
+    contribution and the aggregated commitment is the plain group sum over ranks.  The only exchange is
+    ONE all_gather of this rank's commitments (13 / 18 group elements); no polynomial crosses xGMI.
+
+    Returns {"instance": uint8[world, n_inst, rec] per-instance commitments (wires, [h_1, h_2,] z,
+    [prod_lookup]), "aggregated": uint8[W + 2, rec] (split-quotient commitments, opening, shifted opening)}."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    commits = hp.prove()
+    rec, nc, W = hp.rec, hp.ncommit, hp.W
+    n_inst = nc - (W + 2)                       # slots committed per instance; the last W + 2 slots aggregate
+    if world == 1:
+        allc = commits.view(1, nc, rec)
+    else:
+        allc = _all_gather_bytes(commits, world, group).view(world, nc, rec)
+    fq = hp.fq_bytes
+    fq_id = 1 if hp.curve == lib.BN254 else 3
+    import numpy as np
+
+    one_limbs = np.zeros(fq // 8, dtype=np.uint64)
+    one_limbs[0] = 1
+    one = torch.from_numpy(lib.field_op(fq_id, "to_mont", one_limbs).view(np.uint8)).to(allc.device)
+    agg = torch.zeros(W + 2, rec, dtype=torch.uint8, device=allc.device)
+    # affine (x, y, flag) -> XYZZ partial (x, y, 1, 1), identity -> zeros; then the same fold as a sharded MSM
+    parts = torch.zeros(W + 2, world, 4 * fq, dtype=torch.uint8, device=allc.device)
+    src = allc[:, n_inst:, :].transpose(0, 1)    # [slot][rank][rec]
+    finite = (src[:, :, 2 * fq:2 * fq + 4].sum(dim=2, dtype=torch.int32) == 0).unsqueeze(-1)
+    parts[:, :, :2 * fq] = src[:, :, :2 * fq]
+    parts[:, :, 2 * fq:3 * fq] = one
+    parts[:, :, 3 * fq:] = one
+    parts = (parts * finite).contiguous()
+    for j in range(W + 2):
+        lib.g1_sum_partials(hp.curve, parts[j].data_ptr(), world, agg[j].data_ptr(), stream=hp.stream)
+    return {"instance": allc[:, :n_inst, :], "aggregated": agg}

@@ -38,8 +38,17 @@ def quot_domain_size(n: int, num_wire_types: int) -> int:
     return m
 
 
-def _dev(a: np.ndarray) -> torch.Tensor:
+def _dev(a) -> torch.Tensor:
+    """field elements -> flat int64 device tensor (numpy (count, 4) uint64, or already a device tensor)"""
+    if isinstance(a, torch.Tensor):
+        return a.reshape(-1).cuda()
     return torch.from_numpy(np.ascontiguousarray(a).view(np.int64).reshape(-1)).cuda()
+
+
+def _host(a) -> np.ndarray:
+    if isinstance(a, torch.Tensor):
+        return a.cpu().numpy().view(np.uint64).reshape(-1, 4)
+    return a
 
 
 class PlonkHotPath:
@@ -78,17 +87,17 @@ class PlonkHotPath:
         # proving key, coefficient form, resident (preprocess(), snark.rs:492-580)
         self.selectors = _dev(rand_fr(NSEL * n, 11)).view(NSEL, n * 4)
         self.sigmas = _dev(rand_fr(W * n, 12)).view(W, n * 4)
-        self.k = rand_fr(W, 13)
+        self.k = _host(rand_fr(W, 13))
         # witness-dependent inputs: wire values, permutation-product values, public input values on H
         self.wire_vals = _dev(rand_fr(W * n, 14)).view(W, n * 4)
         self.perm_vals = _dev(rand_fr(n, 15))
         self.pub_vals = _dev(rand_fr(n, 16))
         # host-side randomness and transcript outputs, fixed for the synthetic run
         self.blind = _dev(rand_fr(64, 17))
-        self.ch = rand_fr(5 if ultra else 4, 18)   # alpha, beta, gamma, [tau,] alpha_base
-        self.zeta = rand_fr(1, 19)[0]
-        self.zeta_omega = rand_fr(1, 20)[0]
-        self.lin_coeffs = rand_fr(32, 21)
+        self.ch = _host(rand_fr(5 if ultra else 4, 18))   # alpha, beta, gamma, [tau,] alpha_base
+        self.zeta = _host(rand_fr(1, 19))[0]
+        self.zeta_omega = _host(rand_fr(1, 20))[0]
+        self.lin_coeffs = _host(rand_fr(32, 21))
         if ultra:
             # plookup_pk: range_table, key_table, table_dom_sep, q_dom_sep polynomials (snark.rs:508-521)
             self.table_polys = _dev(rand_fr(4 * n, 22)).view(4, n * 4)

@@ -62,3 +62,66 @@ def test_two_rank_sharded_prove_matches_single():
     for p in procs:
         p.join(timeout=30)
     assert sorted(res) == [(0, True), (1, True)], res
+
+
+def _batch_worker(rank, world, port, log_n, q):
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from jellyfish_amd import dist as jdist
+        from jellyfish_amd import lib as L
+        from jellyfish_amd import prover_path as P
+        from oracle import pyref as R
+        from tests.util import mont_arr, pt_arr, rand_fr_mont
+
+        torch.cuda.set_device(0)
+        L.load_library()
+        L.init(0)
+        cv = R.BLS12_381
+        n = 1 << log_n
+        beta = mont_arr(cv.fr, [97531])[0]
+        srs = L.Srs.gen_for_testing(1, beta, pt_arr(cv, cv.g), n + 8)
+        rand = lambda count, seed: rand_fr_mont(cv, count, 30000 + 1000 * rank + seed)   # a different circuit per rank
+        hp = P.UltraPlonkHotPath(1, log_n, srs, rand)
+        res = jdist.batch_prove_one_per_rank(hp, L)
+        hp.stream.sync()
+        own = hp.commits.cpu().numpy().copy()
+        q.put((rank, own, res["instance"].cpu().numpy().copy(), res["aggregated"].cpu().numpy().copy(), hp.rec))
+    except Exception as e:
+        q.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_batch_prove_one_circuit_per_rank_aggregates_by_group_sum():
+    """BASELINE config 5 shape at world size 2 (both ranks on cuda:0): per-instance commitments are gathered,
+    the split-quotient and opening commitments are the group sums of the per-rank contributions."""
+    import torch.multiprocessing as mp
+
+    from oracle import coracle as C
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_batch_worker, args=(r, 2, port, 6, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=100) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=30)
+    assert all(len(r) == 5 for r in res), res
+    rec = res[0][4]
+    own = [r[1].reshape(18, rec) for r in res]
+    for r in res:
+        inst, agg = r[2], r[3]
+        assert inst.shape == (2, 10, rec) and agg.shape == (8, rec)
+        for k in range(2):
+            assert (inst[k] == own[k][:10]).all()
+        for j in range(8):
+            a = own[0][10 + j][:96].view(np.uint64)
+            b = own[1][10 + j][:96].view(np.uint64)
+            assert (agg[j][:96].view(np.uint64) == C.ec_add(1, a, b)).all(), j
