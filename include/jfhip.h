@@ -194,6 +194,28 @@ int32_t jfhip_plonk_quotient_ultra_device(int32_t curve_id, uint32_t log_n, uint
                                           const void *d_pub_input, const void *d_plookup, const uint64_t *k_mont,
                                           const uint64_t *challenges_mont, void *d_quot, jfhip_stream *stream);
 
+/* ---- grand-product builders (next row) ------------------------------------ */
+
+/* Replaces the serial loop (one field division per row) of
+ * Arithmetization::compute_prod_permutation_polynomial, relation/src/constraint_system.rs:1394-1420,
+ * up to (not including) its final ifft_in_place:
+ *     d_out[0] = 1,  d_out[j+1] = d_out[j] * prod_i (w[i][j] + gamma + beta * id[i][j])
+ *                                          / prod_i (w[i][j] + gamma + beta * sigma[i][j]),  j < n - 1.
+ * DEVICE arrays laid out [wire type][n], n = 2^log_n: d_wire_vals = witness[wire_variable(i, j)],
+ * d_id_perm = extended_id_permutation[i*n + j], d_sigma_vals = extended_id_permutation at the permuted
+ * position (perm_i*n + perm_j).  beta, gamma: host, Montgomery.  Asynchronous on `stream`. */
+int32_t jfhip_plonk_perm_product_device(int32_t curve_id, uint32_t log_n, uint32_t num_wire_types,
+                                        const void *d_wire_vals, const void *d_id_perm, const void *d_sigma_vals,
+                                        const uint64_t *beta_mont, const uint64_t *gamma_mont, void *d_out,
+                                        jfhip_stream *stream);
+
+/* Same for Arithmetization::compute_lookup_prod_polynomial, relation/src/constraint_system.rs:1516-1575:
+ * d_lookup_wire[n] = merged lookup witness values (merged_lookup_wire_value), d_table[n] = merged lookup
+ * table, d_sorted[2n - 1] = the sorted vector; d_out[n] with d_out[0] = d_out[n-1] = 1. */
+int32_t jfhip_plonk_lookup_product_device(int32_t curve_id, uint32_t log_n, const void *d_lookup_wire,
+                                          const void *d_table, const void *d_sorted, const uint64_t *beta_mont,
+                                          const uint64_t *gamma_mont, void *d_out, jfhip_stream *stream);
+
 /* ---- device-resident polynomial glue (next row) -------------------------- */
 
 /* Replaces the witness-polynomial division of open() / compute_batched_witness_polynomial_commitment

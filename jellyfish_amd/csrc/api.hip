@@ -669,6 +669,36 @@ int32_t jfhip_plonk_quotient_ultra_device(int32_t curve_id, uint32_t log_n, uint
                                        (const uint32_t*)d_plookup, k_mont, ch, (uint32_t*)d_quot, st);
 }
 
+int32_t jfhip_plonk_perm_product_device(int32_t curve_id, uint32_t log_n, uint32_t num_wire_types,
+                                        const void* d_wire_vals, const void* d_id_perm, const void* d_sigma_vals,
+                                        const uint64_t* beta, const uint64_t* gamma, void* d_out,
+                                        jfhip_stream* stream) {
+    JF_TRY(check_curve(curve_id));
+    if (!d_wire_vals || !d_id_perm || !d_sigma_vals || !beta || !gamma || !d_out) {
+        set_error("null argument");
+        return JFHIP_ERR_INVALID;
+    }
+    JF_STREAM(st, stream);
+    std::lock_guard<std::mutex> lk(st->mu);
+    return plonk_perm_product_device(curve_id, log_n, num_wire_types, (const uint32_t*)d_wire_vals,
+                                     (const uint32_t*)d_id_perm, (const uint32_t*)d_sigma_vals, beta, gamma,
+                                     (uint32_t*)d_out, st);
+}
+
+int32_t jfhip_plonk_lookup_product_device(int32_t curve_id, uint32_t log_n, const void* d_lookup_wire,
+                                          const void* d_table, const void* d_sorted, const uint64_t* beta,
+                                          const uint64_t* gamma, void* d_out, jfhip_stream* stream) {
+    JF_TRY(check_curve(curve_id));
+    if (!d_lookup_wire || !d_table || !d_sorted || !beta || !gamma || !d_out) {
+        set_error("null argument");
+        return JFHIP_ERR_INVALID;
+    }
+    JF_STREAM(st, stream);
+    std::lock_guard<std::mutex> lk(st->mu);
+    return plonk_lookup_product_device(curve_id, log_n, (const uint32_t*)d_lookup_wire, (const uint32_t*)d_table,
+                                       (const uint32_t*)d_sorted, beta, gamma, (uint32_t*)d_out, st);
+}
+
 int32_t jfhip_poly_divide_linear_device(int32_t curve_id, const void* d_coeffs, size_t n, const uint64_t* point,
                                         void* d_out, jfhip_stream* stream) {
     JF_TRY(check_curve(curve_id));

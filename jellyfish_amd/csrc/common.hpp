@@ -111,6 +111,12 @@ int32_t plonk_quotient_ultra_device(int32_t curve, uint32_t log_n, uint32_t log_
                                     const uint32_t* sig, const uint32_t* wires, const uint32_t* zperm,
                                     const uint32_t* pi, const uint32_t* lookup, const uint64_t* k_mont,
                                     const uint64_t* challenges_mont, uint32_t* out, jfhip_stream* st);
+int32_t plonk_perm_product_device(int32_t curve, uint32_t log_n, uint32_t nw, const uint32_t* wires,
+                                  const uint32_t* idp, const uint32_t* sig, const uint64_t* beta, const uint64_t* gamma,
+                                  uint32_t* out, jfhip_stream* st);
+int32_t plonk_lookup_product_device(int32_t curve, uint32_t log_n, const uint32_t* f, const uint32_t* t,
+                                    const uint32_t* s, const uint64_t* beta, const uint64_t* gamma, uint32_t* out,
+                                    jfhip_stream* st);
 int32_t open_witness_device(int32_t curve, const uint32_t* d_coeffs, size_t n, const uint32_t* d_point,
                             uint32_t* d_witness, uint32_t* d_eval, jfhip_stream* st);
 int32_t poly_lincomb_device(int32_t curve, const uint32_t* const* d_polys, const size_t* lens, size_t count,

@@ -35,7 +35,7 @@ SYMBOLS = [
     "jfhip_stream_sync", "jfhip_stream_raw", "jfhip_stream_wrap", "jfhip_srs_load", "jfhip_srs_load_device",
     "jfhip_srs_gen_for_testing", "jfhip_srs_free", "jfhip_srs_len", "jfhip_srs_window_bits", "jfhip_srs_read",
     "jfhip_msm", "jfhip_msm_batch", "jfhip_msm_batch_device", "jfhip_msm_device", "jfhip_msm_partial_device", "jfhip_g1_sum_partials",
-    "jfhip_kzg_open", "jfhip_ntt", "jfhip_ntt_device", "jfhip_plonk_quotient_turbo_device", "jfhip_plonk_quotient_ultra_device", "jfhip_poly_divide_linear_device",
+    "jfhip_kzg_open", "jfhip_ntt", "jfhip_ntt_device", "jfhip_plonk_quotient_turbo_device", "jfhip_plonk_quotient_ultra_device", "jfhip_plonk_perm_product_device", "jfhip_plonk_lookup_product_device", "jfhip_poly_divide_linear_device",
     "jfhip_poly_lincomb_device", "jfhip_poly_eval_batch_device", "jfhip_field_op", "jfhip_g1_op", "jfhip_probe",
     "jfhip_set_profiling", "jfhip_last_phase_ms", "jfhip_phase_name",
 ]
@@ -290,6 +290,22 @@ def plonk_quotient_ultra_device(curve: int, log_n: int, log_m: int, d_selectors:
     _check(load_library().jfhip_plonk_quotient_ultra_device(curve, log_n, log_m, _vp(d_selectors), _vp(d_sigmas),
                                                             _vp(d_wires), _vp(d_prod_perm), _vp(d_pub_input),
                                                             _vp(d_plookup), _p(k), _p(ch), _vp(d_quot), _sh(stream)))
+
+
+def plonk_perm_product_device(curve: int, log_n: int, num_wire_types: int, d_wire_vals: int, d_id_perm: int,
+                              d_sigma_vals: int, beta_mont, gamma_mont, d_out: int, stream: Stream | None = None):
+    """permutation grand product values on H (see include/jfhip.h)"""
+    b, g = _u64(beta_mont), _u64(gamma_mont)
+    _check(load_library().jfhip_plonk_perm_product_device(curve, log_n, num_wire_types, _vp(d_wire_vals), _vp(d_id_perm),
+                                                          _vp(d_sigma_vals), _p(b), _p(g), _vp(d_out), _sh(stream)))
+
+
+def plonk_lookup_product_device(curve: int, log_n: int, d_lookup_wire: int, d_table: int, d_sorted: int, beta_mont,
+                                gamma_mont, d_out: int, stream: Stream | None = None):
+    """Plookup grand product values on H (see include/jfhip.h)"""
+    b, g = _u64(beta_mont), _u64(gamma_mont)
+    _check(load_library().jfhip_plonk_lookup_product_device(curve, log_n, _vp(d_lookup_wire), _vp(d_table), _vp(d_sorted),
+                                                            _p(b), _p(g), _vp(d_out), _sh(stream)))
 
 
 def poly_divide_linear_device(curve: int, d_coeffs: int, n: int, point_mont, d_out: int, stream: Stream | None = None):

@@ -56,7 +56,7 @@ class PlonkHotPath:
 
     ultra = False: TurboPlonk, 5 wire types, 13 selectors: 13 commitments.
     ultra = True:  UltraPlonk with Plookup, 6 wire types, 14 selectors, 4 table polynomials in the
-    proving key and the online oracles h_1, h_2, prod_lookup (rounds 1.5 / 2.5, prover.rs:99-178):
+    proving key and the online polynomials h_1, h_2, prod_lookup (rounds 1.5 / 2.5, prover.rs:99-178):
     11 iNTTs of size n, 35 coset NTTs of size 8n, 18 commitments."""
 
     def __init__(self, curve: int, log_n: int, srs: "L.Srs", rand_fr, stream: "L.Stream | None" = None,

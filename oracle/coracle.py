@@ -34,7 +34,8 @@ def lib():
         _LIB = ctypes.CDLL(so)
         for name in ("jfo_fp_binop", "jfo_fp_unop", "jfo_ec_add", "jfo_ec_mul", "jfo_ec_on_curve", "jfo_srs_gen",
                      "jfo_msm", "jfo_msm_naive", "jfo_poly_eval", "jfo_open_witness", "jfo_ntt", "jfo_domain_root",
-                     "jfo_threads", "jfo_field_limbs", "jfo_plonk_quotient_turbo", "jfo_plonk_quotient_ultra"):
+                     "jfo_threads", "jfo_field_limbs", "jfo_plonk_quotient_turbo", "jfo_plonk_quotient_ultra", "jfo_plonk_perm_product",
+                     "jfo_plonk_lookup_product"):
             getattr(_LIB, name).restype = ctypes.c_int
     return _LIB
 
@@ -173,6 +174,25 @@ def plonk_quotient_ultra(curve: int, log_n: int, log_m: int, sel, sig, wires, zp
                                           _p(lookup), _p(k), _p(alpha), _p(beta), _p(gamma), _p(tau), _p(alpha_base),
                                           _p(o), threads or nthreads()) == 0
     return o
+
+
+def plonk_perm_product(curve: int, log_n: int, wires, idp, sig, beta, gamma):
+    """wires / idp / sig: [nw][n][4]; returns the n grand-product values on H"""
+    wires, idp, sig, beta, gamma = (_u64(x) for x in (wires, idp, sig, beta, gamma))
+    n = 1 << log_n
+    nw = wires.size // (4 * n)
+    out = np.zeros((n, 4), dtype=np.uint64)
+    assert lib().jfo_plonk_perm_product(curve, log_n, nw, _p(wires), _p(idp), _p(sig), _p(beta), _p(gamma), _p(out)) == 0
+    return out
+
+
+def plonk_lookup_product(curve: int, log_n: int, f, t, s, beta, gamma):
+    f, t, s, beta, gamma = (_u64(x) for x in (f, t, s, beta, gamma))
+    n = 1 << log_n
+    assert s.size == (2 * n - 1) * 4
+    out = np.zeros((n, 4), dtype=np.uint64)
+    assert lib().jfo_plonk_lookup_product(curve, log_n, _p(f), _p(t), _p(s), _p(beta), _p(gamma), _p(out)) == 0
+    return out
 
 
 def domain_root(curve: int, log_n: int):

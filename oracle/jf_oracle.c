@@ -706,3 +706,70 @@ int jfo_plonk_quotient_ultra(int curve, int log_n, int log_m, const uint64_t *se
     return quot_core(curve, log_n, log_m, 6, sel, sig, wires, zperm, pi, lookup, k, alpha, beta, gamma, tau, alpha_base,
                      out, threads);
 }
+
+/* ---- grand products -------------------------------------------------------
+ * Serial restatements, one division per row as the reference:
+ * compute_prod_permutation_polynomial relation/src/constraint_system.rs:1394-1420 (before its ifft),
+ * arrays [wire type][n]. */
+int jfo_plonk_perm_product(int curve, int log_n, int nw, const uint64_t *wires, const uint64_t *idp,
+                           const uint64_t *sig, const uint64_t *beta, const uint64_t *gamma, uint64_t *out) {
+    ensure_init();
+    if ((curve != 0 && curve != 1) || nw < 1) return -1;
+    const f4_ctx *fr = fr_of(curve);
+    const size_t n = (size_t)1 << log_n;
+    memcpy(out, fr->r1, 32);
+    for (size_t j = 0; j + 1 < n; j++) {
+        uint64_t a[4], b[4], t[4], u[4];
+        memcpy(a, fr->r1, 32);
+        memcpy(b, fr->r1, 32);
+        for (int i = 0; i < nw; i++) {
+            const size_t e = 4 * ((size_t)i * n + j);
+            f4_add(fr, t, wires + e, gamma);
+            f4_mul(fr, u, beta, idp + e);
+            f4_add(fr, u, u, t);
+            f4_mul(fr, a, a, u);
+            f4_mul(fr, u, beta, sig + e);
+            f4_add(fr, u, u, t);
+            f4_mul(fr, b, b, u);
+        }
+        f4_inv(fr, b, b);
+        f4_mul(fr, a, a, b);
+        f4_mul(fr, out + 4 * (j + 1), out + 4 * j, a);
+    }
+    return 0;
+}
+
+/* compute_lookup_prod_polynomial relation/src/constraint_system.rs:1516-1575 (before its ifft):
+ * f[n] merged lookup witness, t[n] merged table, s[2n-1] sorted vector. */
+int jfo_plonk_lookup_product(int curve, int log_n, const uint64_t *f, const uint64_t *t, const uint64_t *s,
+                             const uint64_t *beta, const uint64_t *gamma, uint64_t *out) {
+    ensure_init();
+    if (curve != 0 && curve != 1) return -1;
+    const f4_ctx *fr = fr_of(curve);
+    const size_t n = (size_t)1 << log_n;
+    uint64_t b1[4], gb[4];
+    f4_add(fr, b1, fr->r1, beta);
+    f4_mul(fr, gb, gamma, b1);
+    memcpy(out, fr->r1, 32);
+    for (size_t j = 0; j + 2 < n; j++) {
+        uint64_t a[4], b[4], u[4];
+        f4_add(fr, a, gamma, f + 4 * j);
+        f4_mul(fr, a, a, b1);
+        f4_mul(fr, u, beta, t + 4 * (j + 1));
+        f4_add(fr, u, u, t + 4 * j);
+        f4_add(fr, u, u, gb);
+        f4_mul(fr, a, a, u);
+        f4_mul(fr, u, beta, s + 4 * (j + 1));
+        f4_add(fr, u, u, s + 4 * j);
+        f4_add(fr, b, u, gb);
+        f4_mul(fr, u, beta, s + 4 * (n + j));
+        f4_add(fr, u, u, s + 4 * (n - 1 + j));
+        f4_add(fr, u, u, gb);
+        f4_mul(fr, b, b, u);
+        f4_inv(fr, b, b);
+        f4_mul(fr, a, a, b);
+        f4_mul(fr, out + 4 * (j + 1), out + 4 * j, a);
+    }
+    if (n > 1) memcpy(out + 4 * (n - 1), fr->r1, 32);
+    return 0;
+}

@@ -488,3 +488,40 @@ def quotient_evals_ultra(cv: Curve, log_n: int, log_m: int, sel, sig, wires, zpe
         t = ((t_circ + t_perm_1 + res1) * zh_inv[i % ratio] + t_perm_2 + res2) % r
         out.append(alpha_base * t % r)
     return out
+
+
+# ----------------------------------------------------------------------------------
+# Grand products: values on H before the reference's final ifft
+# ----------------------------------------------------------------------------------
+
+
+def perm_product(cv: Curve, wires, idp, sig, beta, gamma):
+    """compute_prod_permutation_polynomial, relation/src/constraint_system.rs:1394-1420.
+    wires / idp / sig: [nw][n] integers (witness values, extended_id_permutation, its permuted values)."""
+    r = cv.fr.p
+    n = len(wires[0])
+    out = [1]
+    for j in range(n - 1):
+        a = b = 1
+        for i in range(len(wires)):
+            t = (wires[i][j] + gamma) % r
+            a = a * (t + beta * idp[i][j]) % r
+            b = b * (t + beta * sig[i][j]) % r
+        out.append(out[-1] * a % r * pow(b, -1, r) % r)
+    return out
+
+
+def lookup_product(cv: Curve, f, t, s, beta, gamma):
+    """compute_lookup_prod_polynomial, relation/src/constraint_system.rs:1516-1575.
+    f: merged lookup witness [n], t: merged table [n], s: sorted vector [2n-1]."""
+    r = cv.fr.p
+    n = len(t)
+    b1 = (1 + beta) % r
+    gb = gamma * b1 % r
+    out = [1]
+    for j in range(n - 2):
+        a = b1 * (gamma + f[j]) % r * (gb + t[j] + beta * t[j + 1]) % r
+        b = (gb + s[j] + beta * s[j + 1]) % r * (gb + s[n - 1 + j] + beta * s[n + j]) % r
+        out.append(out[-1] * a % r * pow(b, -1, r) % r)
+    out.append(1)
+    return out
