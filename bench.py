@@ -98,13 +98,13 @@ def prove_section(L, torch, dist, world, stream, beta):
         ts.append(dt * 1e3)
     sec = {
         "workload": "TurboPlonk BN254 2^20 gates, one instance: 7 iNTT(2^20) + 25 coset NTT(2^23, zero-extended) "
-                    "+ quotient evaluation + coset iNTT(2^23) + 13 commitments (~2^20 points) + 12 divisions "
-                    "+ 2 linear combinations, all device resident",
+                    "+ permutation grand product + quotient evaluation + coset iNTT(2^23) + 13 commitments (~2^20 points) "
+                    "+ 10 evaluations + 2 linear combinations + 2 divisions, all device resident",
         "n_gpus": world,
         "sharding": "single GPU" if world == 1 else "commitment point ranges over %d ranks (SRS replicated), "
                     "transforms and quotient replicated" % world,
         "ms": round(float(np.median(ts)), 3), "runs_ms": [round(t, 3) for t in ts],
-        "excluded": "host transcript, RNG, serial grand product (inputs here); witness upload",
+        "excluded": "host transcript and RNG (challenges / blinding are inputs); witness upload",
         "commitments_sha": hashlib.sha256(bytes(commits.cpu().numpy().tobytes())).hexdigest()[:16]}
     srs_p.free()
     del hp
@@ -153,11 +153,11 @@ def batch_prove_section(L, torch, dist, world, rank, stream, log_g):
             dt = float(tt.item())
         ts.append(dt * 1e3)
     sec = {"workload": "batch_prove, %d UltraPlonk (Plookup) BLS12-381 circuits of 2^%d gates, one per GPU: per circuit "
-                       "11 iNTT(n) + 35 coset NTT(8n) + Plookup quotient + coset iNTT(8n) + 18 commitments + 27 evaluations"
+                       "11 iNTT(n) + 35 coset NTT(8n) + 2 grand products + Plookup quotient + coset iNTT(8n) + 18 commitments + 27 evaluations"
                        % (world, log_g),
            "n_gpus": world, "ms": round(float(np.median(ts)), 3), "runs_ms": [round(t, 3) for t in ts],
            "circuits_per_s": round(world / (float(np.median(ts)) * 1e-3), 3),
-           "excluded": "host transcript, RNG, grand products and sorted lookup vector (inputs here)",
+           "excluded": "host transcript, RNG and the sorted lookup vector merge (inputs here)",
            "aggregated_sha": hashlib.sha256(bytes(res["aggregated"].cpu().numpy().tobytes())).hexdigest()[:16]}
     srs_p.free()
     del hp

@@ -7,9 +7,10 @@ extension, the quotient evaluation, 1 inverse coset NTT of size 8n, 13 commitmen
 10 evaluations, 2 linear combinations and 2 divisions by (X - z).
 
 What stays on the host in the reference stays out of this sequence: the transcript (challenges are
-inputs here), the RNG (blinding coefficients are inputs), and the serial grand product of
-compute_prod_permutation_polynomial (relation/src/constraint_system.rs:1394-1420; its evaluations
-are an input).  Every polynomial stays resident in HBM between steps; only 13 group elements and 10
+inputs here) and the RNG (blinding coefficients are inputs).  The grand products of
+compute_prod_permutation_polynomial / compute_lookup_prod_polynomial
+(relation/src/constraint_system.rs:1394-1420, 1516-1575) run on the device from the wire values and
+the permutation / sorted-vector data.  Every polynomial stays resident in HBM between steps; only 13 group elements and 10
 field elements would cross PCIe.  Used by bench.py with synthetic inputs of the reference bench's
 shape (plonk/benches/bench.rs:29-46); all arithmetic is in libjfhip.
 """
@@ -88,9 +89,11 @@ class PlonkHotPath:
         self.selectors = _dev(rand_fr(NSEL * n, 11)).view(NSEL, n * 4)
         self.sigmas = _dev(rand_fr(W * n, 12)).view(W, n * 4)
         self.k = _host(rand_fr(W, 13))
-        # witness-dependent inputs: wire values, permutation-product values, public input values on H
+        # witness-dependent inputs: wire values and public input values on H; the extended identity permutation and
+        # its permuted values (extended_id_permutation / wire_permutation, relation/src/constraint_system.rs:1403-1417)
         self.wire_vals = _dev(rand_fr(W * n, 14)).view(W, n * 4)
-        self.perm_vals = _dev(rand_fr(n, 15))
+        self.id_perm_vals = _dev(rand_fr(W * n, 15)).view(W, n * 4)
+        self.sigma_vals = _dev(rand_fr(W * n, 25)).view(W, n * 4)
         self.pub_vals = _dev(rand_fr(n, 16))
         # host-side randomness and transcript outputs, fixed for the synthetic run
         self.blind = _dev(rand_fr(64, 17))
@@ -101,10 +104,12 @@ class PlonkHotPath:
         if ultra:
             # plookup_pk: range_table, key_table, table_dom_sep, q_dom_sep polynomials (snark.rs:508-521)
             self.table_polys = _dev(rand_fr(4 * n, 22)).view(4, n * 4)
-            # values on H of the sorted-vector halves h_1, h_2 and of the lookup grand product (host-built in the
-            # reference: relation/src/constraint_system.rs:1516-1624; inputs here)
-            self.h_vals = _dev(rand_fr(2 * n, 23)).view(2, n * 4)
-            self.plprod_vals = _dev(rand_fr(n, 24))
+            # merged lookup witness, merged table and the sorted vector (2n - 1 values; h_1 = sorted[..n],
+            # h_2 = sorted[n-1..]) -- the hash-map merge sort is host work in the reference
+            # (relation/src/constraint_system.rs:1577-1624) and an input here
+            self.lookup_wire_vals = _dev(rand_fr(n, 23))
+            self.merged_table_vals = _dev(rand_fr(n, 24))
+            self.sorted_vals = _dev(rand_fr(2 * n - 1, 26))
         # working storage
         ln = n + 4                          # room for the n+2 / n+3 coefficients of a blinded polynomial
         self.ln = ln
@@ -159,7 +164,6 @@ class PlonkHotPath:
         # Round 1 (prover.rs:77-91): wire polynomials = iNTT of wire values, blind, commit; pub input poly
         self.ntt_buf[:W].copy_(self.wire_vals)
         self.ntt_buf[W].copy_(self.pub_vals)
-        self.ntt_buf[W + 1].copy_(self.perm_vals)
         L.ntt_device(c, self.ntt_buf.data_ptr(), self.log_n, W + 1, inverse=True, stream=st)
         self.wire_polys[:, :n4].copy_(self.ntt_buf[:W])
         for j in range(W):
@@ -169,22 +173,29 @@ class PlonkHotPath:
         slot += W
         if ultra:
             # Round 1.5 (prover.rs:99-124): h_1, h_2 = iNTT of the sorted-vector halves, blind (bound 2), commit
-            self.ntt_buf[:2].copy_(self.h_vals)
+            self.ntt_buf[0].copy_(self.sorted_vals[:n4])
+            self.ntt_buf[1].copy_(self.sorted_vals[n4 - 4:2 * n4 - 4])
             L.ntt_device(c, self.ntt_buf.data_ptr(), self.log_n, 2, inverse=True, stream=st)
             self.h_polys[:, :n4].copy_(self.ntt_buf[:2])
             for j in range(2):
                 self._blind(self.h_polys[j], 3, 6 + 2 * j)
             self._commit_many(slot, [self.h_polys[j][:(n + 3) * 4] for j in range(2)])
             slot += 2
-        # Round 2 (prover.rs:128-142): permutation product polynomial (values are an input), commit
+        # Round 2 (prover.rs:128-142): permutation grand product on H (constraint_system.rs:1394-1420), iNTT, commit
+        beta_gamma = self.ch[1:3]
+        L.plonk_perm_product_device(c, self.log_n, W, self.wire_vals.data_ptr(), self.id_perm_vals.data_ptr(),
+                                    self.sigma_vals.data_ptr(), beta_gamma[0], beta_gamma[1],
+                                    self.ntt_buf[W + 1].data_ptr(), stream=st)
         L.ntt_device(c, self.ntt_buf[W + 1].data_ptr(), self.log_n, 1, inverse=True, stream=st)
         self.perm_poly[:n4].copy_(self.ntt_buf[W + 1])
         self._blind(self.perm_poly, 3, 10 if ultra else W)
         self._commit_many(slot, [self.perm_poly[:(n + 3) * 4]])
         slot += 1
         if ultra:
-            # Round 2.5 (prover.rs:147-178): lookup grand-product polynomial, blind (bound 2), commit
-            self.ntt_buf[0].copy_(self.plprod_vals)
+            # Round 2.5 (prover.rs:147-178): lookup grand product on H (constraint_system.rs:1516-1575), iNTT, blind, commit
+            L.plonk_lookup_product_device(c, self.log_n, self.lookup_wire_vals.data_ptr(),
+                                          self.merged_table_vals.data_ptr(), self.sorted_vals.data_ptr(), beta_gamma[0],
+                                          beta_gamma[1], self.ntt_buf[0].data_ptr(), stream=st)
             L.ntt_device(c, self.ntt_buf.data_ptr(), self.log_n, 1, inverse=True, stream=st)
             self.plprod_poly[:n4].copy_(self.ntt_buf[0])
             self._blind(self.plprod_poly, 3, 12)

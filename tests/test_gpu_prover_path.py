@@ -36,7 +36,10 @@ def test_prover_path_matches_oracle(hip, cv):
     blind = rand(64, 17)
     wires = C.ntt(cid, rand(5 * n, 14).reshape(5, n, 4), log_n, True)
     pub = C.ntt(cid, rand(n, 16).reshape(1, n, 4), log_n, True)[0]
-    perm = C.ntt(cid, rand(n, 15).reshape(1, n, 4), log_n, True)[0]
+    ch = rand(4, 18)
+    perm_vals = C.plonk_perm_product(cid, log_n, rand(5 * n, 14).reshape(5, n, 4), rand(5 * n, 15).reshape(5, n, 4),
+                                     rand(5 * n, 25).reshape(5, n, 4), ch[1], ch[2])
+    perm = C.ntt(cid, perm_vals.reshape(1, n, 4), log_n, True)[0]
     wire_polys = [np.concatenate([wires[j], blind[2 * j:2 * j + 2]]) for j in range(5)]
     perm_poly = np.concatenate([perm, blind[10:13]])
     for j in range(5):
@@ -51,7 +54,6 @@ def test_prover_path_matches_oracle(hip, cv):
 
     sel_c = rand(13 * n, 11).reshape(13, n, 4)
     sig_c = rand(5 * n, 12).reshape(5, n, 4)
-    ch = rand(4, 18)
     quot_ev = C.plonk_quotient_turbo(cid, log_n, log_m, np.array([coset(p) for p in sel_c]),
                                      np.array([coset(p) for p in sig_c]), np.array([coset(p) for p in wire_polys]),
                                      coset(perm_poly), coset(pub), rand(5, 13), *ch)
@@ -129,9 +131,15 @@ def test_ultra_prover_path_matches_oracle(hip, cv):
     commit = lambda poly: C.msm(cid, srs_host[:len(poly)], poly)
     wire_polys = [np.concatenate([w, blind[2 * j:2 * j + 2]]) for j, w in enumerate(intt(rand(6 * n, 14)))]
     pub = intt(rand(n, 16))[0]
-    h_polys = [np.concatenate([h, blind[12 + 4 * j:15 + 4 * j]]) for j, h in enumerate(intt(rand(2 * n, 23)))]
-    perm_poly = np.concatenate([intt(rand(n, 15))[0], blind[20:23]])
-    plprod_poly = np.concatenate([intt(rand(n, 24))[0], blind[24:27]])
+    ch = rand(5, 18)
+    srt = rand(2 * n - 1, 26)
+    h_polys = [np.concatenate([h, blind[12 + 4 * j:15 + 4 * j]])
+               for j, h in enumerate(intt(np.concatenate([srt[:n], srt[n - 1:]])))]
+    perm_vals = C.plonk_perm_product(cid, log_n, rand(6 * n, 14).reshape(6, n, 4), rand(6 * n, 15).reshape(6, n, 4),
+                                     rand(6 * n, 25).reshape(6, n, 4), ch[1], ch[2])
+    perm_poly = np.concatenate([intt(perm_vals)[0], blind[20:23]])
+    plprod_vals = C.plonk_lookup_product(cid, log_n, rand(n, 23), rand(n, 24), srt, ch[1], ch[2])
+    plprod_poly = np.concatenate([intt(plprod_vals)[0], blind[24:27]])
     for j in range(6):
         assert (got[j] == commit(wire_polys[j])).all(), j
     assert (got[6] == commit(h_polys[0])).all() and (got[7] == commit(h_polys[1])).all()
@@ -149,7 +157,7 @@ def test_ultra_prover_path_matches_oracle(hip, cv):
     lookup = [coset(p) for p in tab_c] + [coset(h_polys[0]), coset(h_polys[1]), coset(plprod_poly)]
     quot_ev = C.plonk_quotient_ultra(cid, log_n, log_m, np.array([coset(p) for p in sel_c]),
                                      np.array([coset(p) for p in sig_c]), np.array([coset(p) for p in wire_polys]),
-                                     coset(perm_poly), coset(pub), np.array(lookup), rand(6, 13), *rand(5, 18))
+                                     coset(perm_poly), coset(pub), np.array(lookup), rand(6, 13), *ch)
     quot = C.ntt(cid, quot_ev.reshape(1, m, 4), log_m, True, h)[0]
     chunks = [quot[j * (n + 2):(j + 1) * (n + 2)] for j in range(6)]
     for j in range(6):
