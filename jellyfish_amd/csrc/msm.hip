@@ -15,6 +15,8 @@
 //   * buckets are folded by sum_k k*B_k = running sums per lane + a tree.
 // All group arithmetic is exact (curve.hpp), so the affine result is the unique group
 // element and equals arkworks' bit for bit.
+#include <stdlib.h>
+
 #include "common.hpp"
 #include "curve.hpp"
 
@@ -74,7 +76,7 @@ JF_DEV int32_t signed_digit(const uint32_t (&v)[N], int w, int c, uint32_t& carr
 // PASS = 0: coarse histogram only.  PASS = 1: reserve + scatter entries.
 template <class Cv, int PASS>
 __global__ __launch_bounds__(256) void k_msm_coarse(const uint32_t* __restrict__ scalars, uint32_t n, DigitPlan pl,
-                                                    uint32_t table_n, uint32_t offset,
+                                                    uint32_t tile_scalars, uint32_t table_n, uint32_t offset,
                                                     uint32_t* __restrict__ gcount /*PASS0: counts, PASS1: cursors*/,
                                                     uint2* __restrict__ entries) {
     using Fr = typename Cv::Fr;
@@ -83,9 +85,10 @@ __global__ __launch_bounds__(256) void k_msm_coarse(const uint32_t* __restrict__
     const uint32_t nb = 1u << pl.coarse_bits;
     for (uint32_t k = threadIdx.x; k < nb; k += 256) hist[k] = 0;
     __syncthreads();
-    const uint32_t tile0 = blockIdx.x * SORT_TILE_SCALARS;
+    const uint32_t tile0 = blockIdx.x * tile_scalars;
+    const int reps = (int)(tile_scalars / 256);
 
-    for (int rep = 0; rep < SORT_TILE_SCALARS / 256; rep++) {
+    for (int rep = 0; rep < reps; rep++) {
         uint32_t i = tile0 + rep * 256 + threadIdx.x;
         if (i < n) {
             Fp<Fr> s = fp_from_mont<Fr>(fp_load<Fr>(scalars + (size_t)i * Fr::N));
@@ -111,7 +114,7 @@ __global__ __launch_bounds__(256) void k_msm_coarse(const uint32_t* __restrict__
         hist[k] = 0;
     }
     __syncthreads();
-    for (int rep = 0; rep < SORT_TILE_SCALARS / 256; rep++) {
+    for (int rep = 0; rep < reps; rep++) {
         uint32_t i = tile0 + rep * 256 + threadIdx.x;
         if (i < n) {
             Fp<Fr> s = fp_from_mont<Fr>(fp_load<Fr>(scalars + (size_t)i * Fr::N));
@@ -778,6 +781,9 @@ static int32_t msm_partial_t(const jfhip_srs* srs, size_t offset, const uint32_t
     pl.c = c;
     pl.W = W;
     pl.coarse_bits = (c - 1) - 8;
+    static const int env_cb = getenv("JFHIP_MSM_COARSE_BITS") ? atoi(getenv("JFHIP_MSM_COARSE_BITS")) : -1;
+    static const int env_tile = getenv("JFHIP_MSM_TILE") ? atoi(getenv("JFHIP_MSM_TILE")) : 0;
+    if (env_cb >= 0 && env_cb < pl.coarse_bits) pl.coarse_bits = env_cb;
     if (pl.coarse_bits < 0) pl.coarse_bits = 0;
     if (pl.coarse_bits > MAX_COARSE_BITS) pl.coarse_bits = MAX_COARSE_BITS;
     pl.fine_bits = (c - 1) - pl.coarse_bits;
@@ -810,12 +816,13 @@ static int32_t msm_partial_t(const jfhip_srs* srs, size_t offset, const uint32_t
 
     JF_HIP(hipMemsetAsync(counts, 0, ((size_t)nb + 1) * 4, st->s));
     JF_HIP(hipMemsetAsync(buckets, 0, (size_t)B * XZ * 4, st->s));
-    const unsigned tiles = (unsigned)((n + SORT_TILE_SCALARS - 1) / SORT_TILE_SCALARS);
-    hipLaunchKernelGGL((k_msm_coarse<Cv, 0>), dim3(tiles), dim3(256), 0, st->s, d_scalars, (uint32_t)n, pl,
+    const uint32_t tile_scalars = env_tile >= 256 ? (uint32_t)(env_tile / 256 * 256) : (uint32_t)SORT_TILE_SCALARS;
+    const unsigned tiles = (unsigned)((n + tile_scalars - 1) / tile_scalars);
+    hipLaunchKernelGGL((k_msm_coarse<Cv, 0>), dim3(tiles), dim3(256), 0, st->s, d_scalars, (uint32_t)n, pl, tile_scalars,
                        (uint32_t)srs->n, (uint32_t)offset, counts, entries);
     hipLaunchKernelGGL(k_msm_coarse_scan, dim3(1), dim3(1024), 0, st->s, counts, nb, cbase, cursor, offs + B);
     pt.mark();
-    hipLaunchKernelGGL((k_msm_coarse<Cv, 1>), dim3(tiles), dim3(256), 0, st->s, d_scalars, (uint32_t)n, pl,
+    hipLaunchKernelGGL((k_msm_coarse<Cv, 1>), dim3(tiles), dim3(256), 0, st->s, d_scalars, (uint32_t)n, pl, tile_scalars,
                        (uint32_t)srs->n, (uint32_t)offset, cursor, entries);
     {
         // refinement levels over the fine bits: one level if <= 8 bits, else two

@@ -1,0 +1,24 @@
+"""Developer probe: MSM phase timings at 2^k points (BN254)."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from jellyfish_amd import lib as L
+import bench
+L.init(0)
+L.set_profiling(True)
+for logn in [int(x) for x in sys.argv[1:]] or [24]:
+    n = 1 << logn
+    beta = bench.uniform_fr(1, 1, bench.BN254_R)[0]
+    srs = L.Srs.gen_for_testing(0, beta, bench.BN254_G, n)
+    sc = torch.from_numpy(bench.uniform_fr(n, 2, bench.BN254_R).view(np.int64)).cuda()
+    out = torch.zeros(128, dtype=torch.uint8, device="cuda")
+    st = L.Stream()
+    for _ in range(3):
+        torch.cuda.synchronize(); t = time.time()
+        L.msm_device(srs, sc.data_ptr(), n, out.data_ptr(), stream=st); st.sync()
+        dt = time.time() - t
+    ph = L.last_phase_ms(st, 0)
+    print(f"msm 2^{logn} c={srs.window_bits} {dt*1e3:.2f} ms {n/dt/1e6:.1f} Mpts/s", {k: round(v, 3) for k, v in ph.items()},
+          "sha", __import__("hashlib").sha256(out.cpu().numpy().tobytes()).hexdigest()[:8], flush=True)
+    srs.free()
