@@ -249,6 +249,11 @@ int32_t jfhip_field_op(int32_t field_id, int32_t op, const uint64_t *a, const ui
 /* op: 0 out = P + Q (packed affine, host), 1 out = k * P (k: Fr Montgomery, passed as Q). */
 int32_t jfhip_g1_op(int32_t curve_id, int32_t op, const uint64_t *P, const uint64_t *Q, uint64_t *out);
 
+/* Host-only: the Keccak-f[1600] permutation on 25 little-endian u64 lanes, in place.  Used by the host side of the
+ * prover for the Merlin transcript behind `StandardTranscript` (plonk/src/transcript/standard.rs:14-39, crate merlin);
+ * no device work. */
+int32_t jfhip_keccak_f1600(uint64_t *state25);
+
 /* Peak-rate probes used by bench.py for the roofline denominators:
  * kind 0: v_mad_u64_u32 multiply-adds/s (INT32 VALU), kind 1: device copy bytes/s,
  * kind 2: Montgomery multiplications/s of the field given in `arg` (field_id). */

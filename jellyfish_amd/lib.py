@@ -37,7 +37,7 @@ SYMBOLS = [
     "jfhip_msm", "jfhip_msm_batch", "jfhip_msm_batch_device", "jfhip_msm_device", "jfhip_msm_partial_device", "jfhip_g1_sum_partials",
     "jfhip_kzg_open", "jfhip_ntt", "jfhip_ntt_device", "jfhip_plonk_quotient_turbo_device", "jfhip_plonk_quotient_ultra_device", "jfhip_plonk_perm_product_device", "jfhip_plonk_lookup_product_device", "jfhip_poly_divide_linear_device",
     "jfhip_poly_lincomb_device", "jfhip_poly_eval_batch_device", "jfhip_field_op", "jfhip_g1_op", "jfhip_probe",
-    "jfhip_set_profiling", "jfhip_last_phase_ms", "jfhip_phase_name",
+    "jfhip_set_profiling", "jfhip_last_phase_ms", "jfhip_phase_name", "jfhip_keccak_f1600",
 ]
 
 
@@ -382,3 +382,9 @@ def last_phase_ms(stream: Stream | None = None, kind: int = 0) -> dict:
         name = load_library().jfhip_phase_name(kind, i).decode()
         out[name or f"phase{i}"] = arr[i]
     return out
+
+
+def keccak_f1600(state: bytearray) -> None:
+    """in-place Keccak-f[1600] on a 200-byte state (host code in libjfhip)"""
+    buf = (ctypes.c_uint64 * 25).from_buffer(state)
+    _check(load_library().jfhip_keccak_f1600(buf))

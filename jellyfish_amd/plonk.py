@@ -1,0 +1,620 @@
+"""TurboPlonk `PlonkKzgSnark::{preprocess, prove}` with every polynomial operation on the device.
+
+Host-side mirror of the reference interface (same names, argument meaning and error behaviour):
+  * `PlonkCircuit`                       relation/src/constraint_system.rs:347-470, 558-790, 831-884, 943-981, 1116-1187
+  * `PlonkKzgSnark.universal_setup_for_testing / preprocess / prove`
+                                          plonk/src/proof_system/snark.rs:447-488, 492-580, 587-613 (-> 163-430)
+  * prover rounds                         plonk/src/proof_system/prover.rs:77-91, 128-142, 183-229, 299-413, 457-488,
+                                          491-661, 894-1015
+The host keeps what the reference keeps on one thread: the Merlin transcript (`StandardTranscript`), the RNG draws for
+the blinding factors (same order), a handful of scalar formulas.  Everything that touches a polynomial runs in libjfhip on
+the GPU and stays resident in HBM between rounds: witness gather, iNTTs, blinding, the permutation grand product, 25
+coset NTTs, the quotient evaluation, the coset iNTT, quotient splitting, 13 commitments (Pippenger MSM), evaluations,
+linearisation and the two opening quotients.  Per proof 13 group elements and 10 field elements cross PCIe, plus the
+witness upload.  There is no CPU path: without libjfhip / a GPU every call raises.
+
+Checked against oracle/plonk_ref.py (byte-identical proofs from the same RNG stream; proofs verify) in
+tests/test_gpu_plonk.py.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+
+from . import hostglue as H
+from . import lib as L
+from .transcript import MerlinTranscript
+
+GATE_WIDTH = 4
+N_TURBO_PLONK_SELECTORS = 13
+
+
+class PlonkError(RuntimeError):
+    pass
+
+
+def _sel(q_lc=(0, 0, 0, 0), q_mul=(0, 0), q_hash=(0, 0, 0, 0), q_o=0, q_c=0, q_ecc=0):
+    return tuple(q_lc) + tuple(q_mul) + tuple(q_hash) + (q_o, q_c, q_ecc)
+
+
+class PlonkCircuit:
+    """TurboPlonk constraint system (host side).  Variables 0 / 1 hold the constants 0 / 1."""
+
+    def __init__(self, curve: int):
+        self.cp = H.CURVES[curve]
+        self.r = self.cp.r
+        self.num_wire_types = GATE_WIDTH + 1
+        self.witness: list[int] = [0, 1]
+        self._gates: list[tuple] = []
+        self._wires: list[list[int]] = [[] for _ in range(GATE_WIDTH + 1)]
+        self.pub_input_gate_ids: list[int] = []
+        self._n = 0
+        self.enforce_constant(0, 0)
+        self.enforce_constant(1, 1)
+
+    @classmethod
+    def new_turbo_plonk(cls, curve: int) -> "PlonkCircuit":
+        return cls(curve)
+
+    # ---- builder ---------------------------------------------------------------------------------
+    def _check_var(self, *vs):
+        for v in vs:
+            if not 0 <= v < len(self.witness):
+                raise PlonkError("VarIndexOutOfBound(%d, %d)" % (v, len(self.witness)))
+
+    def _insert_gate(self, wire_vars, sel):
+        if self._n:
+            raise PlonkError("ModifyFinalizedCircuit")
+        for w, v in zip(self._wires, wire_vars):
+            w.append(v)
+        self._gates.append(sel)
+
+    def num_gates(self) -> int:
+        return len(self._gates)
+
+    def num_vars(self) -> int:
+        return len(self.witness)
+
+    def num_inputs(self) -> int:
+        return len(self.pub_input_gate_ids)
+
+    def zero(self) -> int:
+        return 0
+
+    def one(self) -> int:
+        return 1
+
+    def create_variable(self, val: int) -> int:
+        if self._n:
+            raise PlonkError("ModifyFinalizedCircuit")
+        self.witness.append(val % self.r)
+        return len(self.witness) - 1
+
+    def create_constant_variable(self, val: int) -> int:
+        v = self.create_variable(val)
+        self.enforce_constant(v, val)
+        return v
+
+    def create_public_variable(self, val: int) -> int:
+        v = self.create_variable(val)
+        self.set_variable_public(v)
+        return v
+
+    def set_variable_public(self, var: int):
+        self._check_var(var)
+        self.pub_input_gate_ids.append(self.num_gates())
+        self._insert_gate((0, 0, 0, 0, var), _sel(q_o=1))
+
+    def enforce_constant(self, var: int, constant: int):
+        self._check_var(var)
+        self._insert_gate((0, 0, 0, 0, var), _sel(q_c=constant % self.r, q_o=1))
+
+    def add_gate(self, a: int, b: int, c: int):
+        self._check_var(a, b, c)
+        self._insert_gate((a, b, 0, 0, c), _sel(q_lc=(1, 1, 0, 0), q_o=1))
+
+    def add(self, a: int, b: int) -> int:
+        self._check_var(a, b)
+        c = self.create_variable(self.witness[a] + self.witness[b])
+        self.add_gate(a, b, c)
+        return c
+
+    def sub_gate(self, a: int, b: int, c: int):
+        self._check_var(a, b, c)
+        self._insert_gate((a, b, 0, 0, c), _sel(q_lc=(1, self.r - 1, 0, 0), q_o=1))
+
+    def sub(self, a: int, b: int) -> int:
+        self._check_var(a, b)
+        c = self.create_variable(self.witness[a] - self.witness[b])
+        self.sub_gate(a, b, c)
+        return c
+
+    def mul_gate(self, a: int, b: int, c: int):
+        self._check_var(a, b, c)
+        self._insert_gate((a, b, 0, 0, c), _sel(q_mul=(1, 0), q_o=1))
+
+    def mul(self, a: int, b: int) -> int:
+        self._check_var(a, b)
+        c = self.create_variable(self.witness[a] * self.witness[b])
+        self.mul_gate(a, b, c)
+        return c
+
+    def enforce_bool(self, a: int):
+        self._check_var(a)
+        self._insert_gate((a, a, 0, 0, a), _sel(q_mul=(1, 0), q_o=1))
+
+    def enforce_equal(self, a: int, b: int):
+        self._check_var(a, b)
+        self._insert_gate((a, b, 0, 0, 0), _sel(q_lc=(1, self.r - 1, 0, 0), q_o=1))
+
+    def power5_gate(self, a: int) -> int:
+        """c = a^5 through the q_hash selector (FifthRootGate shape)"""
+        self._check_var(a)
+        c = self.create_variable(pow(self.witness[a], 5, self.r))
+        self._insert_gate((a, 0, 0, 0, c), _sel(q_hash=(1, 0, 0, 0), q_o=1))
+        return c
+
+    def pad_gates(self, n: int):
+        for _ in range(n):
+            self._insert_gate((0, 0, 0, 0, 0), _sel(q_lc=(1, self.r - 1, 0, 0), q_o=1))
+
+    def public_input(self) -> list[int]:
+        out = self._wires[GATE_WIDTH] if not self._n else self.wire_variables[GATE_WIDTH]
+        return [self.witness[int(out[g])] for g in self.pub_input_gate_ids]
+
+    # ---- finalisation ----------------------------------------------------------------------------
+    def is_finalized(self) -> bool:
+        return self._n != 0
+
+    def eval_domain_size(self) -> int:
+        if not self._n:
+            raise PlonkError("UnfinalizedCircuit")
+        return self._n
+
+    def srs_size(self) -> int:
+        return self.eval_domain_size() + 2
+
+    def finalize_for_arithmetization(self):
+        """pad to a power of two, io gates to the front, wire permutation (constraint_system.rs:1167-1187);
+        the field-valued tables (k * g^j, sigma values, selector polynomials) are built on the device by preprocess"""
+        if self._n:
+            return
+        n = 1
+        while n < self.num_gates():
+            n <<= 1
+        if n.bit_length() - 1 > self.cp.two_adicity:
+            raise PlonkError("DomainCreationError")
+        W = self.num_wire_types
+        pad = n - self.num_gates()
+        wv = np.zeros((W, n), dtype=np.int64)
+        for i in range(W):
+            wv[i, :n - pad] = self._wires[i]
+        gates = self._gates + [_sel()] * pad
+        uniq: dict[tuple, int] = {}
+        gate_kind = np.fromiter((uniq.setdefault(g, len(uniq)) for g in gates), dtype=np.int64, count=n)
+        for gate_id in range(len(self.pub_input_gate_ids)):
+            io = self.pub_input_gate_ids[gate_id]
+            if io > gate_id:
+                gate_kind[[gate_id, io]] = gate_kind[[io, gate_id]]
+                wv[:, [gate_id, io]] = wv[:, [io, gate_id]]
+                self.pub_input_gate_ids[gate_id] = gate_id
+        # wire permutation: the wires of one variable, in (wire type, gate) order, form a cycle
+        flat = wv.reshape(-1)
+        order = np.argsort(flat, kind="stable")
+        sv = flat[order]
+        differs = sv[1:] != sv[:-1]
+        is_start = np.concatenate(([True], differs))
+        is_last = np.concatenate((differs, [True]))
+        pos = np.arange(flat.size)
+        group_start = np.maximum.accumulate(np.where(is_start, pos, 0))
+        nxt = np.roll(order, -1)
+        nxt[is_last] = order[group_start[is_last]]
+        perm = np.empty_like(order)
+        perm[order] = nxt
+        self.wire_variables = wv
+        self.wire_permutation = perm            # flat index wire_id * n + gate_id of the next wire in the cycle
+        self.gate_kind = gate_kind
+        self.gate_kinds = list(uniq.keys())
+        self.k = H.compute_coset_representatives(self.cp, W, n)
+        self._wires = self._gates = None
+        self._n = n
+        self.log_n = n.bit_length() - 1
+
+    def check_circuit_satisfiability(self, pub_input) -> None:
+        """gate equation on every row (constraint_system.rs:585-603, 894-938); host integers, for tests/small circuits"""
+        if len(pub_input) != self.num_inputs():
+            raise PlonkError("PubInputLenMismatch(%d, %d)" % (len(pub_input), self.num_inputs()))
+        r = self.r
+        pis = dict(zip(self.pub_input_gate_ids, pub_input))
+        for gid in range(self._n):
+            s = self.gate_kinds[int(self.gate_kind[gid])]
+            w = [self.witness[int(self.wire_variables[i][gid])] for i in range(5)]
+            lhs = (pis.get(gid, 0) + sum(s[i] * w[i] for i in range(4)) + s[4] * w[0] * w[1] + s[5] * w[2] * w[3]
+                   + sum(s[6 + i] * pow(w[i], 5, r) for i in range(4)) + s[11] + s[12] * w[0] * w[1] * w[2] * w[3] * w[4])
+            if (lhs - s[10] * w[4]) % r:
+                raise PlonkError("GateCheckFailure(%d)" % gid)
+
+
+# ---------------------------------------------------------------------------------------------------
+
+
+@dataclass
+class UniversalSrs:
+    curve: int
+    powers_of_g: "L.Srs"          # device resident, with its window-multiple table
+    g: tuple
+    h: tuple
+    beta_h: tuple
+
+    def max_degree(self) -> int:
+        return len(self.powers_of_g) - 1
+
+
+@dataclass
+class VerifyingKey:
+    domain_size: int
+    num_inputs: int
+    sigma_comms: list
+    selector_comms: list
+    k: list
+    g: tuple
+    h: tuple
+    beta_h: tuple
+    is_merged: bool = False
+
+    def as_dict(self) -> dict:
+        return dict(domain_size=self.domain_size, num_inputs=self.num_inputs, sigma_comms=self.sigma_comms,
+                    selector_comms=self.selector_comms, k=self.k, g=self.g, h=self.h, beta_h=self.beta_h)
+
+
+@dataclass
+class ProvingKey:
+    curve: int
+    sigmas: torch.Tensor          # (W, n*4) coefficients
+    selectors: torch.Tensor       # (13, n*4) coefficients
+    commit_key: "L.Srs"
+    vk: VerifyingKey
+    # evaluation-form tables the grand product reads (the reference recomputes them from the circuit per proof)
+    id_perm_vals: torch.Tensor = field(repr=False, default=None)
+    sigma_vals: torch.Tensor = field(repr=False, default=None)
+    wire_variables: torch.Tensor = field(repr=False, default=None)
+
+    def domain_size(self) -> int:
+        return self.vk.domain_size
+
+
+@dataclass
+class Proof:
+    curve: int
+    wires_poly_comms: list
+    prod_perm_poly_comm: tuple
+    split_quot_poly_comms: list
+    opening_proof: tuple
+    shifted_opening_proof: tuple
+    wires_evals: list
+    wire_sigma_evals: list
+    perm_next_eval: int
+
+    def as_dict(self) -> dict:
+        return {k: getattr(self, k) for k in ("wires_poly_comms", "prod_perm_poly_comm", "split_quot_poly_comms",
+                                              "opening_proof", "shifted_opening_proof", "wires_evals",
+                                              "wire_sigma_evals", "perm_next_eval")}
+
+    def serialize_compressed(self) -> bytes:
+        """ark-serialize layout of `Proof` (plonk/src/proof_system/structs.rs:54-76); plookup_proof = None"""
+        cp = H.CURVES[self.curve]
+        out = bytearray()
+        out += len(self.wires_poly_comms).to_bytes(8, "little")
+        for c in self.wires_poly_comms:
+            out += H.ser_g1(cp, c)
+        out += H.ser_g1(cp, self.prod_perm_poly_comm)
+        out += len(self.split_quot_poly_comms).to_bytes(8, "little")
+        for c in self.split_quot_poly_comms:
+            out += H.ser_g1(cp, c)
+        out += H.ser_g1(cp, self.opening_proof) + H.ser_g1(cp, self.shifted_opening_proof)
+        for v in (self.wires_evals, self.wire_sigma_evals):
+            out += len(v).to_bytes(8, "little")
+            for x in v:
+                out += H.ser_fr(cp, x)
+        out += H.ser_fr(cp, self.perm_next_eval)
+        out.append(0)
+        return bytes(out)
+
+
+class StandardTranscript:
+    """plonk/src/transcript/{mod.rs:46-186, standard.rs:14-39}"""
+
+    def __init__(self, cp: H.CurveParams, label: bytes = b"PlonkProof"):
+        self.cp = cp
+        self.t = MerlinTranscript(label)
+
+    def append_message(self, label: bytes, msg: bytes):
+        self.t.append_message(label, msg)
+
+    def append_vk_and_pub_input(self, vk: VerifyingKey, pub_input):
+        cp = self.cp
+        self.append_message(b"field size in bits", cp.r.bit_length().to_bytes(4, "little"))
+        self.append_message(b"domain size", vk.domain_size.to_bytes(8, "little"))
+        self.append_message(b"input size", vk.num_inputs.to_bytes(8, "little"))
+        self.append_message(b"SRS G2 element", H.ser_g2(cp, vk.beta_h))
+        self.append_field_elems(b"wire subsets separators", vk.k)
+        self.append_commitments(b"selector commitments", vk.selector_comms)
+        self.append_commitments(b"sigma commitments", vk.sigma_comms)
+        self.append_field_elems(b"public input", pub_input)
+
+    def append_commitments(self, label: bytes, comms):
+        for c in comms:
+            self.append_message(label, H.ser_g1(self.cp, c))
+
+    def append_field_elems(self, label: bytes, xs):
+        for x in xs:
+            self.append_message(label, H.ser_fr(self.cp, x))
+
+    def get_challenge(self, label: bytes) -> int:
+        return int.from_bytes(self.t.challenge_bytes(label, 64), "little") % self.cp.r
+
+
+# ---------------------------------------------------------------------------------------------------
+
+
+def _dev_fr(a: np.ndarray) -> torch.Tensor:
+    return torch.from_numpy(np.ascontiguousarray(a).view(np.int64).reshape(-1)).cuda()
+
+
+_STREAMS: dict = {}
+
+
+def _stream(stream):
+    """the caller's jfhip stream, else one wrapper (and one MSM/NTT workspace) per torch stream, kept for reuse"""
+    if stream is not None:
+        return stream
+    raw = torch.cuda.current_stream().cuda_stream
+    key = (torch.cuda.current_device(), raw)
+    if key not in _STREAMS:
+        _STREAMS[key] = L.Stream(wrap_raw=raw)
+    return _STREAMS[key]
+
+
+def _read_fr(cp, t: torch.Tensor) -> list[int]:
+    return H.fr_from_mont(cp, t.cpu().numpy().view(np.uint64))
+
+
+def _commit_many(srs: "L.Srs", cp, polys, lens, stream) -> list:
+    """batch_commit of device polynomials -> canonical affine points (None = identity)"""
+    rec = (16 * cp.fq_limbs64 + 4 + 15) // 16 * 16
+    out = torch.zeros(len(polys) * rec, dtype=torch.uint8, device="cuda")
+    for p, ln in zip(polys, lens):
+        if ln - 1 > len(srs) - 1:
+            raise PlonkError("poly degree %d is larger than allowed %d" % (ln - 1, len(srs) - 1))
+    if len(polys) == 1:
+        L.msm_device(srs, polys[0].data_ptr(), lens[0], out.data_ptr(), stream=stream)
+    else:
+        L.msm_batch_device(srs, [p.data_ptr() for p in polys], lens, out.data_ptr(), stream=stream)
+    raw = out.cpu().numpy().tobytes()
+    return [H.g1_from_record(cp, raw[i * rec:(i + 1) * rec]) for i in range(len(polys))]
+
+
+def domain_size_ratio(n: int, num_wire_types: int) -> int:
+    """plonk/src/constants.rs:18-20"""
+    return (num_wire_types * (n + 1) + 2) // n + 1
+
+
+class PlonkKzgSnark:
+    @staticmethod
+    def universal_setup_for_testing(curve: int, max_degree: int, beta: int, g=None, h=None) -> UniversalSrs:
+        """[beta^i]g for i <= max_degree on the device, h and [beta]h (snark.rs:447-488).  beta, g, h are arguments
+        (the reference draws them from its RNG)."""
+        cp = H.CURVES[curve]
+        g = g or cp.g1
+        h = h or cp.g2
+        L.load_library()
+        srs = L.Srs.gen_for_testing(curve, H.fr_to_mont(cp, [beta])[0], H.g1_to_mont(cp, g), max_degree + 1)
+        return UniversalSrs(curve, srs, g, h, H.g2_mul(cp, beta, h))
+
+    @staticmethod
+    def preprocess(srs: UniversalSrs, circuit: PlonkCircuit, stream=None):
+        """selector / sigma polynomials and their commitments (snark.rs:492-580), all on the device"""
+        cp = circuit.cp
+        c = cp.curve_id
+        n, log_n, W = circuit.eval_domain_size(), circuit.log_n, circuit.num_wire_types
+        if srs.max_degree() < circuit.srs_size():
+            raise PlonkError("IndexTooLarge")
+        st = _stream(stream)
+        # selector values -> coefficients (compute_selector_polynomials, constraint_system.rs:1359-1372)
+        table = np.stack([H.fr_to_mont(cp, k) for k in circuit.gate_kinds])             # (kinds, 13, 4)
+        sel_vals = np.ascontiguousarray(table[circuit.gate_kind].transpose(1, 0, 2))        # (13, n, 4)
+        selectors = _dev_fr(sel_vals).view(N_TURBO_PLONK_SELECTORS, n * 4)
+        L.ntt_device(c, selectors.data_ptr(), log_n, N_TURBO_PLONK_SELECTORS, inverse=True, stream=st)
+        # extended identity permutation id[i*n + j] = k_i g^j (constraint_system.rs:1116-1132): the forward NTT of k_i X
+        idp = torch.zeros(W, n * 4, dtype=torch.int64, device="cuda")
+        idp[:, 4:8] = _dev_fr(H.fr_to_mont(cp, circuit.k)).view(W, 4)
+        if n > 1:
+            L.ntt_device(c, idp.data_ptr(), log_n, W, inverse=False, stream=st)
+        # extended permutation (constraint_system.rs:1135-1161) and its polynomials (:1374-1392)
+        perm = torch.from_numpy(circuit.wire_permutation).cuda()
+        sigma_vals = idp.view(W * n, 4)[perm].contiguous().view(W, n * 4)
+        sigmas = sigma_vals.clone()
+        L.ntt_device(c, sigmas.data_ptr(), log_n, W, inverse=True, stream=st)
+        comms = _commit_many(srs.powers_of_g, cp, [selectors[j] for j in range(N_TURBO_PLONK_SELECTORS)]
+                             + [sigmas[j] for j in range(W)], [n] * (N_TURBO_PLONK_SELECTORS + W), st)
+        vk = VerifyingKey(n, circuit.num_inputs(), comms[N_TURBO_PLONK_SELECTORS:], comms[:N_TURBO_PLONK_SELECTORS],
+                          list(circuit.k), srs.g, srs.h, srs.beta_h)
+        pk = ProvingKey(c, sigmas, selectors, srs.powers_of_g, vk, idp, sigma_vals,
+                        torch.from_numpy(circuit.wire_variables.reshape(-1)).cuda())
+        return pk, vk
+
+    @staticmethod
+    def prove(rng, circuit: PlonkCircuit, prove_key: ProvingKey, extra_transcript_init_msg: bytes | None = None,
+              stream=None, witness_mont: np.ndarray | None = None) -> Proof:
+        """One TurboPlonk proof (snark.rs:587-613 -> batch_prove_internal :163-430 with one instance).
+        witness_mont: optional pre-converted witness table ((num_vars, 4) uint64 Montgomery), else converted here."""
+        cp = circuit.cp
+        c, r = cp.curve_id, cp.r
+        pk, vk = prove_key, prove_key.vk
+        n = circuit.eval_domain_size()
+        if pk.domain_size() != n:
+            raise PlonkError("proving key domain size %d != expected domain size %d" % (pk.domain_size(), n))
+        if circuit.num_inputs() != vk.num_inputs:
+            raise PlonkError("circuit.num_inputs %d != prove_key.num_inputs %d" % (circuit.num_inputs(), vk.num_inputs))
+        log_n, W = circuit.log_n, circuit.num_wire_types
+        m = 1
+        while m < n * domain_size_ratio(n, W):
+            m <<= 1
+        log_m = m.bit_length() - 1
+        n4 = n * 4
+        ck = pk.commit_key
+        st = _stream(stream)
+        mont = lambda xs: H.fr_to_mont(cp, xs)  # noqa: E731
+        gen = mont([cp.fr_generator])[0]
+        group_gen = pow(cp.two_adic_root, 1 << (cp.two_adicity - log_n), r)
+
+        tr = StandardTranscript(cp)
+        if extra_transcript_init_msg is not None:
+            tr.append_message(b"extra info", extra_transcript_init_msg)
+        pub_input = circuit.public_input()
+        tr.append_vk_and_pub_input(vk, pub_input)
+
+        def mask(poly: torch.Tensor, hiding_bound: int):
+            """mask_polynomial (prover.rs:457-466): + (b_0 + .. + b_h X^h)(X^n - 1); poly has room for n + h + 1"""
+            b = [H.fr_rand(cp, rng) for _ in range(hiding_bound + 1)]
+            k = 4 * (hiding_bound + 1)
+            low = _read_fr(cp, poly[:k])
+            poly[:k] = _dev_fr(mont([(x - y) % r for x, y in zip(low, b)]))
+            poly[n4:n4 + k] = _dev_fr(mont(b))
+
+        # ---- Round 1 (prover.rs:77-91): wire polynomials, public-input polynomial
+        wit = _dev_fr(witness_mont if witness_mont is not None else mont(circuit.witness)).view(-1, 4)
+        wire_vals = wit[pk.wire_variables].view(W, n4)
+        buf = torch.empty(W + 1, n4, dtype=torch.int64, device="cuda")
+        buf[:W].copy_(wire_vals)
+        buf[W].zero_()
+        if pub_input:
+            buf[W, :4 * len(pub_input)] = _dev_fr(mont(pub_input))   # io gates sit in rows 0 .. num_inputs-1
+        L.ntt_device(c, buf.data_ptr(), log_n, W + 1, inverse=True, stream=st)
+        ln = n + 3
+        wire_polys = torch.zeros(W, ln * 4, dtype=torch.int64, device="cuda")
+        wire_polys[:, :n4].copy_(buf[:W])
+        pub_poly = buf[W]
+        for j in range(W):
+            mask(wire_polys[j], 1)
+        wires_poly_comms = _commit_many(ck, cp, [wire_polys[j] for j in range(W)], [n + 2] * W, st)
+        tr.append_commitments(b"witness_poly_comms", wires_poly_comms)
+
+        # ---- Round 2 (prover.rs:128-142; grand product constraint_system.rs:1394-1420)
+        beta = tr.get_challenge(b"beta")
+        gamma = tr.get_challenge(b"gamma")
+        bg = mont([beta, gamma])
+        perm_poly = torch.zeros(ln * 4, dtype=torch.int64, device="cuda")
+        L.plonk_perm_product_device(c, log_n, W, wire_vals.data_ptr(), pk.id_perm_vals.data_ptr(),
+                                    pk.sigma_vals.data_ptr(), bg[0], bg[1], perm_poly.data_ptr(), stream=st)
+        L.ntt_device(c, perm_poly.data_ptr(), log_n, 1, inverse=True, stream=st)
+        mask(perm_poly, 2)
+        prod_perm_poly_comm = _commit_many(ck, cp, [perm_poly], [n + 3], st)[0]
+        tr.append_commitments(b"perm_poly_comms", [prod_perm_poly_comm])
+
+        # ---- Round 3 (prover.rs:183-198, 491-661, 894-943)
+        alpha = tr.get_challenge(b"alpha")
+        NSEL = N_TURBO_PLONK_SELECTORS
+        npolys = NSEL + 2 * W + 2
+        o_sig, o_w, o_z, o_pi = NSEL, NSEL + W, NSEL + 2 * W, NSEL + 2 * W + 1
+        cs = torch.empty(npolys, m * 4, dtype=torch.int64, device="cuda")
+        l4 = ln * 4
+        cs[:, n4:l4].zero_()
+        cs[:NSEL, :n4].copy_(pk.selectors)
+        cs[o_sig:o_w, :n4].copy_(pk.sigmas)
+        cs[o_w:o_z, :l4].copy_(wire_polys)
+        cs[o_z, :l4].copy_(perm_poly)
+        cs[o_pi, :n4].copy_(pub_poly)
+        L.ntt_device(c, cs.data_ptr(), log_m, npolys, inverse=False, coset_mont=gen, in_len=ln, stream=st)
+        quot = torch.zeros(m * 4, dtype=torch.int64, device="cuda")
+        L.plonk_quotient_turbo_device(c, log_n, log_m, cs[0].data_ptr(), cs[o_sig].data_ptr(), cs[o_w].data_ptr(),
+                                      cs[o_z].data_ptr(), cs[o_pi].data_ptr(), mont(vk.k), mont([alpha, beta, gamma, 1]),
+                                      quot.data_ptr(), stream=st)
+        del cs
+        L.ntt_device(c, quot.data_ptr(), log_m, 1, inverse=True, coset_mont=gen, stream=st)
+        expected_degree = W * (n + 1) + 2
+        tail_nonzero = bool(torch.any(quot[(expected_degree + 1) * 4:] != 0).item())
+        top_zero = not bool(torch.any(quot[expected_degree * 4:(expected_degree + 1) * 4] != 0).item())
+        if tail_nonzero or top_zero:
+            raise PlonkError("WrongQuotientPolyDegree(expected %d)" % expected_degree)
+        split = torch.zeros(W, l4, dtype=torch.int64, device="cuda")
+        step = (n + 2) * 4
+        for i in range(W - 1):
+            split[i, :step].copy_(quot[i * step:(i + 1) * step])
+        last_len = expected_degree + 1 - (W - 1) * (n + 2)
+        split[W - 1, :last_len * 4].copy_(quot[(W - 1) * step:(expected_degree + 1) * 4])
+        del quot
+        firsts = _read_fr(cp, split[:, :4].contiguous())
+        last_randomizer = 0
+        for i in range(W - 1):
+            now_randomizer = H.fr_rand(cp, rng)
+            firsts[i] = (firsts[i] - last_randomizer) % r
+            split[i, step:step + 4] = _dev_fr(mont([now_randomizer]))
+            last_randomizer = now_randomizer
+        firsts[W - 1] = (firsts[W - 1] - last_randomizer) % r
+        split[:, :4] = _dev_fr(mont(firsts)).view(W, 4)
+        split_lens = [n + 3] * (W - 1) + [last_len]
+        split_quot_poly_comms = _commit_many(ck, cp, [split[j] for j in range(W)], split_lens, st)
+        tr.append_commitments(b"quot_poly_comms", split_quot_poly_comms)
+
+        # ---- Round 4 (prover.rs:205-229): evaluations
+        zeta = tr.get_challenge(b"zeta")
+        zeta_omega = zeta * group_gen % r
+        evals_dev = torch.zeros((2 * W) * 4, dtype=torch.int64, device="cuda")
+        at_zeta = [(wire_polys[j], n + 2) for j in range(W)] + [(pk.sigmas[j], n) for j in range(W - 1)]
+        L.poly_eval_batch_device(c, [p.data_ptr() for p, _ in at_zeta], [k for _, k in at_zeta], mont([zeta])[0],
+                                 evals_dev.data_ptr(), stream=st)
+        L.poly_eval_batch_device(c, [perm_poly.data_ptr()], [n + 3], mont([zeta_omega])[0],
+                                 evals_dev.data_ptr() + (2 * W - 1) * 32, stream=st)
+        ev = _read_fr(cp, evals_dev)
+        wires_evals, wire_sigma_evals, perm_next_eval = ev[:W], ev[W:2 * W - 1], ev[2 * W - 1]
+        tr.append_field_elems(b"wire_evals", wires_evals)
+        tr.append_field_elems(b"wire_sigma_evals", wire_sigma_evals)
+        tr.append_field_elems(b"perm_next_eval", [perm_next_eval])
+
+        # linearisation polynomial (snark.rs:364-389; prover.rs:299-352, 946-1015), one lincomb on the device
+        vanish_eval = (pow(zeta, n, r) - 1) % r
+        zeta_to_n_plus_2 = (vanish_eval + 1) * zeta % r * zeta % r
+        terms = []
+        coeff = 1
+        for i in range(W):
+            if i:
+                coeff = coeff * zeta_to_n_plus_2 % r
+            terms.append((-vanish_eval * coeff % r, split[i], split_lens[i]))
+        w = wires_evals
+        q_scalars = [w[0], w[1], w[2], w[3], w[0] * w[1], w[2] * w[3], pow(w[0], 5, r), pow(w[1], 5, r), pow(w[2], 5, r),
+                     pow(w[3], 5, r), -w[4], 1, w[0] * w[1] * w[2] * w[3] * w[4]]
+        terms += [(s % r, pk.selectors[j], n) for j, s in enumerate(q_scalars)]
+        lagrange_1_eval = vanish_eval * pow(n * (zeta - 1) % r, -1, r) % r
+        cz = alpha
+        for j in range(W):
+            cz = cz * (w[j] + beta * vk.k[j] % r * zeta + gamma) % r
+        cz = (cz + alpha * alpha % r * lagrange_1_eval) % r
+        terms.append((cz, perm_poly, n + 3))
+        csig = alpha * beta % r * perm_next_eval % r
+        for j in range(W - 1):
+            csig = csig * (w[j] + beta * wire_sigma_evals[j] + gamma) % r
+        terms.append((-csig % r, pk.sigmas[W - 1], n))
+        lin_poly = torch.zeros(l4, dtype=torch.int64, device="cuda")
+        L.poly_lincomb_device(c, [p.data_ptr() for _, p, _ in terms], [k for _, _, k in terms],
+                              mont([s for s, _, _ in terms]), lin_poly.data_ptr(), n + 3, stream=st)
+
+        # ---- Round 5 (prover.rs:356-413, 470-488): batched opening quotients
+        v = tr.get_challenge(b"v")
+        polys = [(lin_poly, n + 3)] + at_zeta
+        vs, cur = [], 1
+        for _ in polys:
+            vs.append(cur)
+            cur = cur * v % r
+        open_poly = torch.zeros(l4, dtype=torch.int64, device="cuda")
+        L.poly_lincomb_device(c, [p.data_ptr() for p, _ in polys], [k for _, k in polys], mont(vs), open_poly.data_ptr(),
+                              n + 3, stream=st)
+        wpoly = torch.zeros(2, l4, dtype=torch.int64, device="cuda")
+        L.poly_divide_linear_device(c, open_poly.data_ptr(), n + 3, mont([zeta])[0], wpoly[0].data_ptr(), stream=st)
+        L.poly_divide_linear_device(c, perm_poly.data_ptr(), n + 3, mont([zeta_omega])[0], wpoly[1].data_ptr(), stream=st)
+        opening_proof, shifted_opening_proof = _commit_many(ck, cp, [wpoly[0][4:], wpoly[1][4:]], [n + 2, n + 2], st)
+
+        return Proof(c, wires_poly_comms, prod_perm_poly_comm, split_quot_poly_comms, opening_proof,
+                     shifted_opening_proof, wires_evals, wire_sigma_evals, perm_next_eval)

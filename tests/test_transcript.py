@@ -1,0 +1,153 @@
+"""Host glue of the prover: Merlin transcript, RNG / field sampling, serialisation (CPU; no GPU compute)."""
+import os
+
+import pytest
+
+from oracle import merlin as OM
+from oracle import plonk_ref as P
+from oracle import pyref as R
+
+MERLIN_KAT = "d5a21972d0d5fe320c0d263fac7fffb8145aa640af6e9bca177c03c7efcf0615"
+
+# Coset representatives k_1..k_4 of the BN254 scalar field as Espresso's public PlonkVerifier contract hard-codes them
+# (COSET_K1..K4; not a file of /root/reference).  They are the first accepted draws of
+# compute_coset_representatives (relation/src/constants.rs:30-84), so they pin the ChaCha20Rng word stream and the
+# ark-ff `Fp::rand` restatement (limb order, top-bit shaving, Montgomery interpretation) at the byte level.
+BN254_COSET_K = [
+    1,
+    0x2F8DD1F1A7583C42C4E12A44E110404C73CA6C94813F85835DA4FB7BB1301D4A,
+    0x1EE678A0470A75A6EAA8FE837060498BA828A3703B311D0F77F010424AFEB025,
+    0x2042A587A90C187B0A087C03E29C968B950B1DB26D5C82D666905A6895790C0A,
+    0x2E2B91456103698ADF57B799969DEA1C8F739DA5D8D40DD3EB9222DB7C81E881,
+]
+
+
+def test_merlin_known_answer_oracle():
+    t = OM.MerlinTranscript(b"test protocol")
+    t.append_message(b"some label", b"some data")
+    assert t.challenge_bytes(b"challenge", 32).hex() == MERLIN_KAT
+
+
+def test_keccak_matches_sha3():
+    import hashlib
+
+    def sha3_256(msg):
+        rate, st = 136, bytearray(200)
+        m = bytearray(msg) + b"\x06"
+        m += b"\x00" * ((-len(m)) % rate)
+        m[-1] ^= 0x80
+        for i in range(0, len(m), rate):
+            for j in range(rate):
+                st[j] ^= m[i + j]
+            OM.keccak_f1600(st)
+        return bytes(st[:32])
+
+    for msg in (b"", b"abc", b"q" * 500):
+        assert sha3_256(msg) == hashlib.sha3_256(msg).digest()
+
+
+def test_merlin_product_matches_oracle():
+    """the product's transcript (Keccak in libjfhip host code) against the oracle and the known answer"""
+    from jellyfish_amd import lib as L
+    from jellyfish_amd.transcript import MerlinTranscript
+
+    L.load_library()
+    t = MerlinTranscript(b"test protocol")
+    t.append_message(b"some label", b"some data")
+    assert t.challenge_bytes(b"challenge", 32).hex() == MERLIN_KAT
+    a, b = MerlinTranscript(b"PlonkProof"), OM.MerlinTranscript(b"PlonkProof")
+    for i in range(40):
+        msg = os.urandom(1 + 37 * i % 400)
+        a.append_message(b"label%d" % i, msg)
+        b.append_message(b"label%d" % i, msg)
+        if i % 7 == 0:
+            assert a.challenge_bytes(b"c", 64) == b.challenge_bytes(b"c", 64)
+
+
+def test_coset_representatives_public_constants():
+    assert P.coset_representatives(R.BN254, 5, 1 << 10) == BN254_COSET_K
+    from jellyfish_amd import hostglue as H
+
+    assert H.compute_coset_representatives(H.BN254, 5, 1 << 10) == BN254_COSET_K
+    assert H.compute_coset_representatives(H.BLS12_381, 6, 64) == P.coset_representatives(R.BLS12_381, 6, 64)
+
+
+def test_hostglue_matches_oracle():
+    from jellyfish_amd import hostglue as H
+
+    for cv, cp in ((R.BN254, H.BN254), (R.BLS12_381, H.BLS12_381)):
+        assert (cp.q, cp.r, cp.g1, cp.g2) == (cv.fq.p, cv.fr.p, cv.g, P.G2_GEN[cv.name])
+        assert P.g2_on_curve(cv, cp.g2)
+        a, b = H.test_rng(), P.test_rng()
+        xs = [H.fr_rand(cp, a) for _ in range(300)]
+        assert xs == [P.fr_rand(cv, b) for _ in range(300)]
+        assert H.fr_from_mont(cp, H.fr_to_mont(cp, xs)) == xs
+        for k in xs[:3]:
+            pt = R.ec_mul(cv, k, cv.g)
+            assert H.ser_g1(cp, pt) == P.ser_g1(cv, pt)
+            assert (H.g1_from_record(cp, H.g1_to_mont(cp, pt).tobytes() + bytes(4))) == pt
+            q2 = P.g2_mul(cv, k, P.G2_GEN[cv.name])
+            assert H.g2_mul(cp, k, cp.g2) == q2 and P.g2_on_curve(cv, q2)
+            assert H.ser_g2(cp, q2) == P.ser_g2(cv, q2)
+        assert H.ser_g1(cp, None) == P.ser_g1(cv, None)
+        # group order annihilates the G2 generator
+        assert P.g2_add(cv, P.g2_mul(cv, cv.fr.p - 1, cp.g2), cp.g2) is None
+
+
+def _circuit(new, cv_p):
+    cs = new()
+    a = cs.create_variable(3)
+    b = cs.create_public_variable(5)
+    c = cs.mul(a, b)
+    d = cs.add(c, a)
+    e = cs.create_public_variable(18)
+    cs.enforce_equal(d, e)
+    f = cs.power5_gate(a)
+    cs.enforce_constant(f, 243)
+    cs.enforce_bool(cs.sub(f, cs.create_variable(242)))
+    for _ in range(9):
+        d = cs.add(d, 1)
+    cs.finalize_for_arithmetization()
+    return cs
+
+
+@pytest.mark.parametrize("cv", [R.BN254, R.BLS12_381], ids=lambda c: c.name)
+def test_oracle_prove_verify(cv):
+    """the restated prover against the restated verifier (prove -> verify, snark.rs tests :852-1064), and rejections"""
+    cs = _circuit(lambda: P.PlonkCircuit(cv), cv.fr.p)
+    assert cs.check_circuit_satisfiability(cs.public_input())
+    beta = 0x1234567890ABCDEF1234567890ABCDEF % cv.fr.p
+    srs = P.universal_setup_for_testing(cv, cs.n + 2, beta)
+    pk, vk = P.preprocess(cv, srs, cs)
+    proof, _, orc = P.prove(cv, P.test_rng(), cs, pk)
+    assert P.verify(cv, vk, cs.public_input(), proof, trapdoor_beta=beta)
+    # split quotient recombines: sum_i X^{i(n+2)} t_i has the blinding cancel (prover.rs:922-940)
+    bad = dict(proof)
+    bad["perm_next_eval"] = (bad["perm_next_eval"] + 1) % cv.fr.p
+    assert not P.verify(cv, vk, cs.public_input(), bad, trapdoor_beta=beta)
+    assert not P.verify(cv, vk, [5, 19], proof, trapdoor_beta=beta)
+    bad = dict(proof)
+    bad["opening_proof"] = R.ec_add(cv, proof["opening_proof"], cv.g)
+    assert not P.verify(cv, vk, cs.public_input(), bad, trapdoor_beta=beta)
+    assert not P.verify(cv, vk, cs.public_input(), proof, extra_msg=b"x", trapdoor_beta=beta)
+    assert len(P.ser_proof(cv, proof)) == 8 + 5 * 8 * cv.fq.limbs64 + 8 * cv.fq.limbs64 + 8 + 5 * 8 * cv.fq.limbs64 \
+        + 2 * 8 * cv.fq.limbs64 + 8 + 5 * 32 + 8 + 4 * 32 + 32 + 1
+
+
+def test_product_circuit_matches_oracle_circuit():
+    """the numpy circuit finalisation of the product against the list-based restatement"""
+    from jellyfish_amd import plonk as JP
+
+    for cv in (R.BN254, R.BLS12_381):
+        a = _circuit(lambda: P.PlonkCircuit(cv), None)
+        b = _circuit(lambda: JP.PlonkCircuit(cv.curve_id), None)
+        n = a.n
+        assert b.eval_domain_size() == n and b.k == a.k and b.public_input() == a.public_input()
+        assert [list(map(int, row)) for row in b.wire_variables] == a.wire_variables
+        assert [int(x) for x in b.wire_permutation] == [w * n + g for (w, g) in a.wire_permutation]
+        assert [list(b.gate_kinds[int(k)]) for k in b.gate_kind] == a.gates
+        b.check_circuit_satisfiability(b.public_input())
+        with pytest.raises(JP.PlonkError):
+            b.check_circuit_satisfiability([5, 19])
+        with pytest.raises(JP.PlonkError):
+            b.create_variable(1)
