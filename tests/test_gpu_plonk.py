@@ -89,20 +89,21 @@ def test_prove_rejects_unsatisfied_and_mismatched(hip):
         JP.PlonkKzgSnark.preprocess(small, cs)
 
 
-def test_bench_circuit_proof_verifies_at_2_16(hip):
-    """gen_circuit_for_bench shape (plonk/benches/bench.rs:29-46: a chain of additions), 2^16 gates, BN254: the proof
-    computed on the device verifies under the restated verifier (size-independent property; the oracle prover would
-    take minutes at this size, its verifier is O(1))."""
+@pytest.mark.parametrize("log_gates", [16, 20])
+def test_bench_circuit_proof_verifies(hip, log_gates):
+    """gen_circuit_for_bench shape (plonk/benches/bench.rs:29-46: a chain of additions), 2^16 and BASELINE config 4's
+    2^20 gates, BN254: the proof computed on the device verifies under the restated verifier (size-independent
+    property; the oracle prover would take hours at this size, its verifier is O(1))."""
     from jellyfish_amd import plonk as JP
 
     cv = R.BN254
     cs = JP.PlonkCircuit.new_turbo_plonk(0)
     a = cs.zero()
-    for _ in range((1 << 16) - 10):
+    for _ in range((1 << log_gates) - 10):
         a = cs.add(a, cs.one())
     cs.finalize_for_arithmetization()
     n = cs.eval_domain_size()
-    assert n == 1 << 16
+    assert n == 1 << log_gates
     srs = JP.PlonkKzgSnark.universal_setup_for_testing(0, n + 2, BETA)
     pk, vk = JP.PlonkKzgSnark.preprocess(srs, cs)
     proof = JP.PlonkKzgSnark.prove(JP.H.test_rng(), cs, pk)
