@@ -242,7 +242,9 @@ int32_t jfhip_poly_lincomb_device(int32_t curve_id, const void *const *d_polys, 
 /* ---- field / group vector ops (test and glue surface) -------------------------------------- */
 
 /* field_id: 0 BN254 Fr, 1 BN254 Fq, 2 BLS12-381 Fr, 3 BLS12-381 Fq.
- * op: 0 add, 1 sub, 2 mul, 3 neg(a), 4 inv(a) (inv(0)=0), 5 from_mont(a), 6 to_mont(a).
+ * op: 0 add, 1 sub, 2 mul, 3 neg(a), 4 inv(a) (inv(0)=0), 5 from_mont(a), 6 to_mont(a);
+ *     7 mul, 8 square(a), 9 sub, 10 ((ab - 2a)(a^2 - b))b - ab computed in the kernels' internal unsaturated
+ *     29-bit-limb form (csrc/fp29.hpp) and converted back: same results as the saturated ops.
  * Host arrays of n elements; exercises the same device arithmetic the MSM/NTT kernels use. */
 int32_t jfhip_field_op(int32_t field_id, int32_t op, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n);
 

@@ -342,7 +342,20 @@ int32_t jfhip_srs_read(const jfhip_srs* srs, size_t offset, size_t n, void* out)
         return JFHIP_ERR_INVALID;
     }
     const size_t pt = 2 * (size_t)fq_bytes(srs->curve);
-    JF_HIP(hipMemcpy(out, (const uint8_t*)srs->table + offset * pt, n * pt, hipMemcpyDeviceToHost));
+    if (!srs->f29 || n == 0) {
+        JF_HIP(hipMemcpy(out, (const uint8_t*)srs->table + offset * pt, n * pt, hipMemcpyDeviceToHost));
+        return JFHIP_OK;
+    }
+    // the table holds the kernels' internal Montgomery factor: convert a copy back to the boundary's form
+    void* tmp = nullptr;
+    JF_HIP(hipMalloc(&tmp, n * pt));
+    hipError_t e = hipMemcpy(tmp, (const uint8_t*)srs->table + offset * pt, n * pt, hipMemcpyDeviceToDevice);
+    int32_t rc = JFHIP_OK;
+    if (e == hipSuccess) rc = table_rescale(srs->curve, (uint32_t*)tmp, n, 0, 0);
+    if (e == hipSuccess && rc == JFHIP_OK) e = hipMemcpy(out, tmp, n * pt, hipMemcpyDeviceToHost);
+    (void)hipFree(tmp);
+    if (rc != JFHIP_OK) return rc;
+    JF_HIP(e);
     return JFHIP_OK;
 }
 
@@ -746,12 +759,12 @@ int32_t jfhip_poly_lincomb_device(int32_t curve_id, const void* const* d_polys, 
 // ---- field / group test surface ---------------------------------------------------------------------
 
 int32_t jfhip_field_op(int32_t field_id, int32_t op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
-    if (field_id < 0 || field_id > 3 || op < 0 || op > 6) {
+    if (field_id < 0 || field_id > 3 || op < 0 || op > 10) {
         set_error("bad field id / op");
         return JFHIP_ERR_INVALID;
     }
     if (n == 0) return JFHIP_OK;
-    if (!a || !out || (op <= 2 && !b)) {
+    if (!a || !out || ((op <= 2 || op >= 7) && !b)) {
         set_error("null argument");
         return JFHIP_ERR_INVALID;
     }
@@ -762,7 +775,7 @@ int32_t jfhip_field_op(int32_t field_id, int32_t op, const uint64_t* a, const ui
     JF_TRY(st->poly_b.ensure(n * el));
     JF_TRY(st->poly_c.ensure(n * el));
     JF_HIP(hipMemcpyAsync(st->poly_a.p, a, n * el, hipMemcpyHostToDevice, st->s));
-    if (op <= 2) JF_HIP(hipMemcpyAsync(st->poly_b.p, b, n * el, hipMemcpyHostToDevice, st->s));
+    if (op <= 2 || op >= 7) JF_HIP(hipMemcpyAsync(st->poly_b.p, b, n * el, hipMemcpyHostToDevice, st->s));
     JF_TRY(field_op_device(field_id, op, st->poly_a.as<uint32_t>(), st->poly_b.as<uint32_t>(),
                            st->poly_c.as<uint32_t>(), n, st->s));
     JF_HIP(hipMemcpyAsync(out, st->poly_c.p, n * el, hipMemcpyDeviceToHost, st->s));

@@ -74,6 +74,7 @@ struct jfhip_srs {
     int32_t W = 0;      // windows
     int device = 0;
     uint32_t* table = nullptr;  // [W][n] packed affine, entry (w, i) = 2^(c*w) * P_i
+    bool f29 = false;           // table coordinates carry the Montgomery factor 2^(29 L) of fp29.hpp instead of 2^(32 N)
 };
 
 namespace jf {
@@ -95,6 +96,7 @@ int32_t msm_partial_device(const jfhip_srs* srs, size_t offset, const uint32_t* 
                            uint32_t* d_out_xyzz, jfhip_stream* st);
 int32_t g1_sum_to_affine(int32_t curve, const uint32_t* d_partials, size_t count, uint32_t* d_out, jfhip_stream* st);
 int32_t srs_build_table(jfhip_srs* srs, const uint32_t* d_points_packed, jfhip_stream* st);
+int32_t table_rescale(int32_t curve, uint32_t* d_pts, size_t count, int up, hipStream_t s);
 int32_t srs_gen_points(int32_t curve, const uint64_t* beta_mont, const uint64_t* g_xy, size_t n, uint32_t* d_out,
                        jfhip_stream* st);
 int32_t srs_pack_points(int32_t curve, const uint8_t* d_raw, size_t n, size_t stride, uint32_t* d_out,

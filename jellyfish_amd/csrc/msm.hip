@@ -19,6 +19,7 @@
 
 #include "common.hpp"
 #include "curve.hpp"
+#include "fp29.hpp"
 
 namespace jf {
 
@@ -377,6 +378,178 @@ __global__ __launch_bounds__(128) void k_msm_accumulate(const uint32_t* __restri
     if (!wroteB) xyzz_store<Cv>(partB + (size_t)t * XZ, XYZZ<Cv>::identity());
 }
 
+// ---- the same accumulation on unsaturated 29-bit limbs (fp29.hpp) ---------------------------------------
+// The window table is stored with the Montgomery factor R' = 2^(29 L) (srs->f29), so a table point only needs its bits
+// re-sliced.  Lazy-reduction bounds, in multiples of p (BN254 Fq, the tightest field: 2^257 = 10.58 p is the contraction
+// limit of f29_mul, whose outputs are < 1.66 p):  X < 7.66, Y < 3.66, ZZ, ZZZ < 1.66;  P = U2 - X + 8p < 9.66,
+// R = S2 - Y + 4p < 5.66, X3 = R^2 - PPP - 2Q + 6p < 7.66, Q - X3 + 8p < 9.66, Y3 = .. - Y PPP + 2p < 3.66.
+template <class Cv>
+struct XYZZ29 {
+    using F = F29<typename Cv::Fq>;
+    F X, Y, ZZ, ZZZ;
+};
+
+template <class Cv>
+JF_DEV XYZZ<Cv> xyzz29_to_std(const XYZZ29<Cv>& a, bool inf) {
+    using Q = typename Cv::Fq;
+    if (inf) return XYZZ<Cv>::identity();
+    XYZZ<Cv> r;
+    r.X = f29_to_fp<Q>(a.X);
+    r.Y = f29_to_fp<Q>(a.Y);
+    r.ZZ = f29_to_fp<Q>(a.ZZ);
+    r.ZZZ = f29_to_fp<Q>(a.ZZZ);
+    return r;
+}
+
+// rare path of the mixed add (P + P or P - P): fall back to the saturated formulas, out of line.  Everything goes
+// in and out BY VALUE: a reference would make the hot loop's accumulator escape into scratch memory.
+template <class Cv>
+struct Rare29 {
+    XYZZ29<Cv> acc;
+    bool inf;
+};
+template <class Cv>
+JF_COLD Rare29<Cv> xyzz29_add_rare(XYZZ29<Cv> acc, F29<typename Cv::Fq> x2, F29<typename Cv::Fq> y2) {
+    using Q = typename Cv::Fq;
+    XYZZ<Cv> a = xyzz29_to_std<Cv>(acc, false);
+    Affine<Cv> q;
+    q.x = f29_to_fp<Q>(x2);
+    q.y = f29_to_fp<Q>(y2);
+    xyzz_add_affine<Cv>(a, q);
+    Rare29<Cv> r;
+    r.inf = a.is_inf();
+    r.acc.X = f29_from_fp<Q>(a.X);
+    r.acc.Y = f29_from_fp<Q>(a.Y);
+    r.acc.ZZ = f29_from_fp<Q>(a.ZZ);
+    r.acc.ZZZ = f29_from_fp<Q>(a.ZZZ);
+    return r;
+}
+
+template <class Cv, int OCC>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void k_msm_accumulate29(const uint32_t* __restrict__ sorted,
+                                                          const uint32_t* __restrict__ off, uint32_t B,
+                                                          const uint32_t* __restrict__ table, uint32_t L,
+                                                          uint32_t* __restrict__ buckets, uint32_t* __restrict__ partA,
+                                                          uint32_t* __restrict__ partB) {
+    using Q = typename Cv::Fq;
+    using F = F29<Q>;
+    constexpr int PT = 2 * Q::N;
+    constexpr int XZ = 4 * Q::N;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t total = off[B];
+    const uint64_t start64 = (uint64_t)t * L;
+    if (start64 >= total) return;
+    const uint32_t start = (uint32_t)start64;
+    const uint32_t end = (uint32_t)((start64 + L < total) ? start64 + L : total);
+
+    uint32_t lo = 0, hi = B;
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (off[mid] <= start) lo = mid;
+        else hi = mid;
+    }
+    uint32_t b = lo;
+    uint32_t b_lo = off[b], b_hi = off[b + 1];
+    while (b_hi <= start) {
+        b++;
+        b_lo = b_hi;
+        b_hi = off[b + 1];
+    }
+
+    XYZZ29<Cv> acc;
+    bool inf = true;
+    uint32_t run_start = start;
+    bool wroteA = false, wroteB = false;
+    F one29 = f29_from_fp<Q>(Fp<Q>::one());
+    F zero29;
+#pragma unroll
+    for (int i = 0; i < F::L; i++) zero29.v[i] = 0;
+
+    auto flush = [&](uint32_t run_end) {
+        bool complete = (run_start == b_lo) && (run_end == b_hi);
+        uint32_t* dst;
+        if (complete) dst = buckets + (size_t)b * XZ;
+        else if (run_start == start) {
+            dst = partA + (size_t)t * XZ;
+            wroteA = true;
+        } else {
+            dst = partB + (size_t)t * XZ;
+            wroteB = true;
+        }
+        xyzz_store<Cv>(dst, xyzz29_to_std<Cv>(acc, inf));
+    };
+
+    for (uint32_t pos = start; pos < end; pos++) {
+        if (pos >= b_hi) {
+            flush(pos);
+            inf = true;
+            run_start = pos;
+            do {
+                b++;
+                b_lo = b_hi;
+                b_hi = off[b + 1];
+            } while (pos >= b_hi);
+        }
+        const uint32_t e = sorted[pos];
+        const Affine<Cv> p = affine_load<Cv>(table + (size_t)(e & 0x7fffffffu) * PT);
+        if (p.is_inf()) continue;
+        F x2 = f29_unpack_bits<Q>(p.x);
+        F y2 = f29_unpack_bits<Q>(p.y);
+        if (e >> 31) y2 = f29_sub<Q, 1>(zero29, y2);   // p - y (y < p)
+        if (inf) {
+            acc.X = x2;
+            acc.Y = y2;
+            acc.ZZ = one29;
+            acc.ZZZ = one29;
+            inf = false;
+            continue;
+        }
+        F U2 = f29_mul<Q>(x2, acc.ZZ);
+        F S2 = f29_mul<Q>(y2, acc.ZZZ);
+        F P = f29_sub<Q, 8>(U2, acc.X);
+        F PP = f29_sqr<Q>(P);
+        if (f29_mulout_is_zero<Q>(PP)) {
+            XYZZ29<Cv> ac = acc;
+            Rare29<Cv> rr = xyzz29_add_rare<Cv>(ac, x2, y2);
+            acc = rr.acc;
+            inf = rr.inf;
+            continue;
+        }
+        F R = f29_sub<Q, 4>(S2, acc.Y);
+        F PPP = f29_mul<Q>(P, PP);
+        F Qv = f29_mul<Q>(acc.X, PP);
+        F X3 = f29_sub3<Q, 6>(f29_sqr<Q>(R), PPP, Qv, Qv);
+        F Y3 = f29_sub<Q, 2>(f29_mul<Q>(R, f29_sub<Q, 8>(Qv, X3)), f29_mul<Q>(acc.Y, PPP));
+        acc.X = X3;
+        acc.Y = Y3;
+        acc.ZZ = f29_mul<Q>(acc.ZZ, PP);
+        acc.ZZZ = f29_mul<Q>(acc.ZZZ, PPP);
+    }
+    flush(end);
+    if (!wroteA) xyzz_store<Cv>(partA + (size_t)t * XZ, XYZZ<Cv>::identity());
+    if (!wroteB) xyzz_store<Cv>(partB + (size_t)t * XZ, XYZZ<Cv>::identity());
+}
+
+// table entries x -> x 2^(+-SHIFT): saturated Montgomery factor R <-> R' (identity entries (0, 0) are unchanged)
+template <class Cv>
+__global__ __launch_bounds__(256) void k_table_rescale(uint32_t* __restrict__ pts, size_t count, int up) {
+    using Q = typename Cv::Fq;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * count) return;
+    Fp<Q> x = fp_load<Q>(pts + i * Q::N);
+    x = up ? fp_scale_up_r29<Q>(x) : fp_scale_down_r29<Q>(x);
+    fp_store<Q>(pts + i * Q::N, x);
+}
+
+int32_t table_rescale(int32_t curve, uint32_t* d_pts, size_t count, int up, hipStream_t s) {
+    if (count == 0) return JFHIP_OK;
+    dim3 grid((unsigned)((2 * count + 255) / 256));
+    if (curve == JFHIP_BN254) hipLaunchKernelGGL((k_table_rescale<Bn254G1>), grid, dim3(256), 0, s, d_pts, count, up);
+    else hipLaunchKernelGGL((k_table_rescale<Bls381G1>), grid, dim3(256), 0, s, d_pts, count, up);
+    JF_HIP(hipGetLastError());
+    return JFHIP_OK;
+}
+
 // buckets spanning >= 2 slices: sum their pieces
 template <class Cv>
 __global__ __launch_bounds__(128) void k_msm_fixup(const uint32_t* __restrict__ off, uint32_t B, uint32_t L,
@@ -674,12 +847,25 @@ static int32_t srs_build_table_t(jfhip_srs* srs, jfhip_stream* st) {
     return JFHIP_OK;
 }
 
+// JFHIP_MSM_F29=0 keeps the table and the accumulation on saturated limbs (A/B measurements)
+static bool env_f29() {
+    const char* e = getenv("JFHIP_MSM_F29");
+    return !(e && e[0] == '0');
+}
+
 int32_t srs_build_table(jfhip_srs* srs, const uint32_t* d_points_packed, jfhip_stream* st) {
     const int PT = 2 * fq_limbs32(srs->curve);
     if (d_points_packed != srs->table)
         JF_HIP(hipMemcpyAsync(srs->table, d_points_packed, srs->n * PT * 4, hipMemcpyDeviceToDevice, st->s));
-    if (srs->curve == JFHIP_BN254) return srs_build_table_t<Bn254G1>(srs, st);
-    return srs_build_table_t<Bls381G1>(srs, st);
+    int32_t rc = (srs->curve == JFHIP_BN254) ? srs_build_table_t<Bn254G1>(srs, st) : srs_build_table_t<Bls381G1>(srs, st);
+    if (rc != JFHIP_OK) return rc;
+    if (env_f29()) {
+        // the whole table moves to the Montgomery factor of the 29-bit-limb arithmetic (fp29.hpp)
+        JF_TRY(table_rescale(srs->curve, srs->table, (size_t)(srs->W > 0 ? srs->W : 1) * srs->n, 1, st->s));
+        JF_HIP(hipStreamSynchronize(st->s));
+        srs->f29 = true;
+    }
+    return JFHIP_OK;
 }
 
 int32_t srs_pack_points(int32_t curve, const uint8_t* d_raw, size_t n, size_t stride, uint32_t* d_out,
@@ -872,9 +1058,16 @@ static int32_t msm_partial_t(const jfhip_srs* srs, size_t offset, const uint32_t
                            st->sorted.as<uint32_t>());
     }
     pt.mark();
-    hipLaunchKernelGGL((k_msm_accumulate<Cv>), dim3((unsigned)((T + 127) / 128)), dim3(128), 0, st->s,
-                       st->sorted.as<uint32_t>(), offs, B, srs->table, (uint32_t)L, buckets,
-                       st->partA.as<uint32_t>(), st->partB.as<uint32_t>());
+    if (srs->f29) {
+        static const int occ = [] { const char* e = getenv("JFHIP_MSM_F29_OCC"); return e ? atoi(e) : 4; }();
+        auto kern = occ == 2 ? k_msm_accumulate29<Cv, 2> : occ == 3 ? k_msm_accumulate29<Cv, 3> : k_msm_accumulate29<Cv, 4>;
+        hipLaunchKernelGGL(kern, dim3((unsigned)((T + 127) / 128)), dim3(128), 0, st->s,
+                           st->sorted.as<uint32_t>(), offs, B, srs->table, (uint32_t)L, buckets,
+                           st->partA.as<uint32_t>(), st->partB.as<uint32_t>());
+    } else
+        hipLaunchKernelGGL((k_msm_accumulate<Cv>), dim3((unsigned)((T + 127) / 128)), dim3(128), 0, st->s,
+                           st->sorted.as<uint32_t>(), offs, B, srs->table, (uint32_t)L, buckets,
+                           st->partA.as<uint32_t>(), st->partB.as<uint32_t>());
     pt.mark();
     hipLaunchKernelGGL((k_msm_fixup<Cv>), dim3((B + 127) / 128), dim3(128), 0, st->s, offs, B, (uint32_t)L,
                        st->partA.as<uint32_t>(), st->partB.as<uint32_t>(), buckets);

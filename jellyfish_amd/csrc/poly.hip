@@ -7,6 +7,7 @@
 // Also: element-wise field ops for the test surface and the peak-rate probes for bench.py.
 #include "common.hpp"
 #include "curve.hpp"
+#include "fp29.hpp"
 
 namespace jf {
 
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(128) void k_field_op(int op, const uint32_t* __rest
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Fp<C> x = fp_load<C>(a + (size_t)i * C::N);
-    Fp<C> y = (op <= 2) ? fp_load<C>(b + (size_t)i * C::N) : Fp<C>::zero();
+    Fp<C> y = (op <= 2 || op >= 7) ? fp_load<C>(b + (size_t)i * C::N) : Fp<C>::zero();
     Fp<C> r;
     switch (op) {
     case 0: r = fp_add<C>(x, y); break;
@@ -270,6 +271,19 @@ __global__ __launch_bounds__(128) void k_field_op(int op, const uint32_t* __rest
     case 3: r = fp_neg<C>(x); break;
     case 4: r = fp_inv<C>(x); break;
     case 5: r = fp_from_mont<C>(x); break;
+    // 29-bit-limb arithmetic of fp29.hpp, through the conversions (test surface)
+    case 7: r = f29_to_fp<C>(f29_mul<C>(f29_from_fp<C>(x), f29_from_fp<C>(y))); break;
+    case 8: r = f29_to_fp<C>(f29_sqr<C>(f29_from_fp<C>(x))); break;
+    case 9: r = f29_to_fp<C>(f29_sub<C, 2>(f29_from_fp<C>(x), f29_from_fp<C>(y))); break;
+    case 10: {  // a lazy chain: ((x y - 2 x) * (x^2 - y + 8p)) * y - x y
+        F29<C> a = f29_from_fp<C>(x), b = f29_from_fp<C>(y);
+        F29<C> ab = f29_mul<C>(a, b);
+        F29<C> t = f29_sub<C, 4>(ab, f29_normalize<C>(f29_dbl_lazy<C>(a)));
+        F29<C> u = f29_sub<C, 8>(f29_sqr<C>(a), b);
+        F29<C> w = f29_mul<C>(f29_mul<C>(t, u), b);
+        r = f29_to_fp<C>(f29_sub<C, 4>(w, ab));
+        break;
+    }
     default: r = fp_to_mont<C>(x); break;
     }
     fp_store<C>(out + (size_t)i * C::N, r);
@@ -315,6 +329,18 @@ __global__ __launch_bounds__(256) void k_probe_copy(const uint4* __restrict__ in
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t stride = (size_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) out[i] = in[i];
+}
+
+template <class C>
+__global__ __launch_bounds__(256) void k_probe_mul29(uint32_t iters, uint32_t seed, uint32_t* __restrict__ out) {
+    F29<C> x = f29_from_fp<C>(Fp<C>::one()), y = f29_from_fp<C>(Fp<C>::r2());
+    x.v[0] ^= (threadIdx.x & 1);
+    y.v[1] ^= seed & 1;
+    for (uint32_t i = 0; i < iters; i++) {
+        x = f29_mul<C>(x, y);
+        y = f29_mul<C>(y, x);
+    }
+    if (x.v[0] == 0x12345u && y.v[1] == 0x777u) out[0] = x.v[2];
 }
 
 template <class C>
@@ -368,6 +394,21 @@ int32_t probe(int32_t kind, int32_t arg, double* out) {
             case 1: hipLaunchKernelGGL((k_probe_mul<Bn254Fq>), dim3(blocks), dim3(256), 0, 0, it, 1u, (uint32_t*)scratch); break;
             case 2: hipLaunchKernelGGL((k_probe_mul<Bls381Fr>), dim3(blocks), dim3(256), 0, 0, it, 1u, (uint32_t*)scratch); break;
             default: hipLaunchKernelGGL((k_probe_mul<Bls381Fq>), dim3(blocks), dim3(256), 0, 0, it, 1u, (uint32_t*)scratch); break;
+            }
+        };
+        launch(8);
+        JF_HIP(hipEventRecord(e0, 0));
+        launch(iters);
+        JF_HIP(hipEventRecord(e1, 0));
+        work = (double)blocks * 256.0 * iters * 2.0;
+    } else if (kind == 3) {
+        const uint32_t iters = 512, blocks = 256 * 8;
+        auto launch = [&](uint32_t it) {
+            switch (arg) {
+            case 0: hipLaunchKernelGGL((k_probe_mul29<Bn254Fr>), dim3(blocks), dim3(256), 0, 0, it, 1u, (uint32_t*)scratch); break;
+            case 1: hipLaunchKernelGGL((k_probe_mul29<Bn254Fq>), dim3(blocks), dim3(256), 0, 0, it, 1u, (uint32_t*)scratch); break;
+            case 2: hipLaunchKernelGGL((k_probe_mul29<Bls381Fr>), dim3(blocks), dim3(256), 0, 0, it, 1u, (uint32_t*)scratch); break;
+            default: hipLaunchKernelGGL((k_probe_mul29<Bls381Fq>), dim3(blocks), dim3(256), 0, 0, it, 1u, (uint32_t*)scratch); break;
             }
         };
         launch(8);

@@ -283,9 +283,34 @@ class ProvingKey:
     id_perm_vals: torch.Tensor = field(repr=False, default=None)
     sigma_vals: torch.Tensor = field(repr=False, default=None)
     wire_variables: torch.Tensor = field(repr=False, default=None)
+    # optional: the 13 selector + W sigma polynomials evaluated on the quotient coset (m = 8n points each), kept in HBM.
+    # The reference recomputes these 18 coset FFTs in every proof (prover.rs:534-544); they depend on the proving key
+    # only, and 288 GB of HBM holds them (18 x 256 MiB at n = 2^20).  Same values, so the same proof bytes.
+    coset_evals: torch.Tensor = field(repr=False, default=None)
 
     def domain_size(self) -> int:
         return self.vk.domain_size
+
+    def quot_domain_size(self) -> int:
+        n, W = self.vk.domain_size, self.sigmas.shape[0]
+        m = 1
+        while m < n * domain_size_ratio(n, W):
+            m <<= 1
+        return m
+
+    def keep_coset_evals(self, stream=None) -> "ProvingKey":
+        """evaluate selectors and sigmas on the quotient coset once and keep them resident (see coset_evals)"""
+        cp = H.CURVES[self.curve]
+        n, m = self.vk.domain_size, self.quot_domain_size()
+        nsel, W = self.selectors.shape[0], self.sigmas.shape[0]
+        ev = torch.empty(nsel + W, m * 4, dtype=torch.int64, device="cuda")
+        ev[:nsel, :n * 4].copy_(self.selectors)
+        ev[nsel:, :n * 4].copy_(self.sigmas)
+        gen = H.fr_to_mont(cp, [cp.fr_generator])[0]
+        L.ntt_device(self.curve, ev.data_ptr(), m.bit_length() - 1, nsel + W, inverse=False, coset_mont=gen, in_len=n,
+                     stream=_stream(stream))
+        self.coset_evals = ev
+        return self
 
 
 @dataclass
@@ -565,20 +590,30 @@ class PlonkKzgSnark:
         # ---- Round 3 (prover.rs:183-198, 491-661, 894-943)
         alpha = tr.get_challenge(b"alpha")
         NSEL = N_TURBO_PLONK_SELECTORS
-        npolys = NSEL + 2 * W + 2
-        o_sig, o_w, o_z, o_pi = NSEL, NSEL + W, NSEL + 2 * W, NSEL + 2 * W + 1
-        cs = torch.empty(npolys, m * 4, dtype=torch.int64, device="cuda")
         l4 = ln * 4
+        if pk.coset_evals is not None:
+            # selector / sigma coset evaluations are resident with the proving key: 7 transforms instead of 25
+            fixed = pk.coset_evals
+            if fixed.shape != (NSEL + W, m * 4):
+                raise PlonkError("proving key coset evaluations have the wrong shape")
+            npolys, o_w = W + 2, 0
+            sel_ptr, sig_ptr = fixed[0].data_ptr(), fixed[NSEL].data_ptr()
+        else:
+            npolys, o_w = NSEL + 2 * W + 2, NSEL + W
+        o_z, o_pi = o_w + W, o_w + W + 1
+        cs = torch.empty(npolys, m * 4, dtype=torch.int64, device="cuda")
         cs[:, n4:l4].zero_()
-        cs[:NSEL, :n4].copy_(pk.selectors)
-        cs[o_sig:o_w, :n4].copy_(pk.sigmas)
+        if pk.coset_evals is None:
+            cs[:NSEL, :n4].copy_(pk.selectors)
+            cs[NSEL:o_w, :n4].copy_(pk.sigmas)
+            sel_ptr, sig_ptr = cs[0].data_ptr(), cs[NSEL].data_ptr()
         cs[o_w:o_z, :l4].copy_(wire_polys)
         cs[o_z, :l4].copy_(perm_poly)
         cs[o_pi, :n4].copy_(pub_poly)
         L.ntt_device(c, cs.data_ptr(), log_m, npolys, inverse=False, coset_mont=gen, in_len=ln, stream=st)
         tick("r3_coset_ntts")
         quot = torch.zeros(m * 4, dtype=torch.int64, device="cuda")
-        L.plonk_quotient_turbo_device(c, log_n, log_m, cs[0].data_ptr(), cs[o_sig].data_ptr(), cs[o_w].data_ptr(),
+        L.plonk_quotient_turbo_device(c, log_n, log_m, sel_ptr, sig_ptr, cs[o_w].data_ptr(),
                                       cs[o_z].data_ptr(), cs[o_pi].data_ptr(), mont(vk.k), mont([alpha, beta, gamma, 1]),
                                       quot.data_ptr(), stream=st)
         del cs

@@ -31,6 +31,9 @@ torch.cuda.synchronize()
 print("setup + preprocess %.2f s" % (time.perf_counter() - t0), flush=True)
 rng = H.test_rng()
 JP.PlonkKzgSnark.prove(rng, cs, pk, witness_mont=wit)
+if os.environ.get("JF_PK_RESIDENT"):
+    pk.keep_coset_evals()
+    print("proving key keeps selector / sigma coset evaluations: %.2f GiB" % (pk.coset_evals.numel() * 8 / 2**30))
 for _ in range(runs):
     torch.cuda.synchronize()
     t0 = time.perf_counter()

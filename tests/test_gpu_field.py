@@ -59,3 +59,23 @@ def test_group_ops(hip, cv):
     # order * G = identity
     rm1 = mont_arr(cv.fr, [cv.fr.p - 1])[0]
     assert pt_from(cv, hip.g1_mul(cv.curve_id, G, rm1)) == R.ec_neg(cv, cv.g)
+
+
+@pytest.mark.parametrize("fname", list(FIELD_ID))
+def test_unsaturated_29bit_arithmetic(hip, fname):
+    """csrc/fp29.hpp (29-bit limbs, lazy reduction, R' = 2^(29 L)) agrees with the saturated arithmetic / the oracle
+    after conversion back: products, squares, differences and a chain that exercises the lazy bounds; edge values
+    0, 1, p - 1 included."""
+    f = FIELDS[fname]
+    fid = FIELD_ID[fname]
+    p = f.p
+    rng = R.SplitMix64(4242 + fid)
+    n = 4096
+    xs = [0, 1, p - 1, p - 1, 0, 2, p - 2] + [rng.field(f) for _ in range(n - 7)]
+    ys = [0, p - 1, p - 1, 1, 5, p - 1, p - 2] + [rng.field(f) for _ in range(n - 7)]
+    A, B = mont_arr(f, xs), mont_arr(f, ys)
+    assert (hip.field_op(fid, "mul29", A, B) == C.fp_binop(fid, "mul", A, B)).all()
+    assert (hip.field_op(fid, "sqr29", A, B) == C.fp_binop(fid, "mul", A, A)).all()
+    assert (hip.field_op(fid, "sub29", A, B) == C.fp_binop(fid, "sub", A, B)).all()
+    want = [(((x * y - 2 * x) * (x * x - y)) * y - x * y) % p for x, y in zip(xs, ys)]
+    assert (hip.field_op(fid, "chain29", A, B) == mont_arr(f, want)).all()

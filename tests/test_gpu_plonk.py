@@ -53,6 +53,10 @@ def test_prove_matches_oracle_and_verifies(hip, cv, size):
     oproof, _, _ = P.prove(cv, P.test_rng(), ocs, opk)
     assert proof.as_dict() == oproof
     assert proof.serialize_compressed() == P.ser_proof(cv, oproof)
+    # selector / sigma coset evaluations resident with the proving key: 7 transforms instead of 25, same bytes
+    pk.keep_coset_evals()
+    assert JP.PlonkKzgSnark.prove(JP.H.test_rng(), cs, pk).serialize_compressed() == P.ser_proof(cv, oproof)
+    pk.coset_evals = None
     pub = cs.public_input()
     assert P.verify(cv, vk.as_dict(), pub, proof.as_dict(), trapdoor_beta=beta)
     # a second proof continues the RNG stream: different blinding, still valid; extra transcript message is bound
@@ -109,3 +113,5 @@ def test_bench_circuit_proof_verifies(hip, log_gates):
     proof = JP.PlonkKzgSnark.prove(JP.H.test_rng(), cs, pk)
     assert P.verify(cv, vk.as_dict(), [], proof.as_dict(), trapdoor_beta=BETA)
     assert len(proof.serialize_compressed()) == 769
+    pk.keep_coset_evals()
+    assert JP.PlonkKzgSnark.prove(JP.H.test_rng(), cs, pk).serialize_compressed() == proof.serialize_compressed()
