@@ -194,6 +194,20 @@ int32_t jfhip_plonk_quotient_ultra_device(int32_t curve_id, uint32_t log_n, uint
                                           const void *d_pub_input, const void *d_plookup, const uint64_t *k_mont,
                                           const uint64_t *challenges_mont, void *d_quot, jfhip_stream *stream);
 
+/* The same loop over ONE SLICE of the quotient coset (SURVEY.md 8e "coset sharding"): with G ranks (G divides
+ * m/n), rank g owns the points i = g (mod G) of the reference's coset {h w_m^i} (prover.rs:524-527, 587-642),
+ * which form the coset of size 2^log_m = m/G with offset h w_m^g; the "next" point (i + m/n) mod m
+ * (prover.rs:594,610) stays inside the slice.  Arguments as the two functions above with that slice's domain:
+ * log_m is the SLICE's size, coset_offset_mont its offset (4 limbs, Montgomery; Fr::GENERATOR itself gives
+ * the functions above), inputs laid out [poly][2^log_m]; num_wire_types 5 (d_plookup ignored, challenges alpha,
+ * beta, gamma, alpha_base) or 6 (challenges alpha, beta, gamma, tau, alpha_base).  No counterpart call in the
+ * reference, which evaluates the whole coset in one rayon loop. */
+int32_t jfhip_plonk_quotient_coset_device(int32_t curve_id, uint32_t num_wire_types, uint32_t log_n, uint32_t log_m,
+                                          const uint64_t *coset_offset_mont, const void *d_selectors,
+                                          const void *d_sigmas, const void *d_wires, const void *d_prod_perm,
+                                          const void *d_pub_input, const void *d_plookup, const uint64_t *k_mont,
+                                          const uint64_t *challenges_mont, void *d_quot, jfhip_stream *stream);
+
 /* ---- grand-product builders (next row) ------------------------------------ */
 
 /* Replaces the serial loop (one field division per row) of

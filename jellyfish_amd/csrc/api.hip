@@ -682,6 +682,29 @@ int32_t jfhip_plonk_quotient_ultra_device(int32_t curve_id, uint32_t log_n, uint
                                        (const uint32_t*)d_plookup, k_mont, ch, (uint32_t*)d_quot, st);
 }
 
+int32_t jfhip_plonk_quotient_coset_device(int32_t curve_id, uint32_t num_wire_types, uint32_t log_n, uint32_t log_m,
+                                          const uint64_t* coset_offset_mont, const void* d_sel, const void* d_sig,
+                                          const void* d_wires, const void* d_zperm, const void* d_pi,
+                                          const void* d_plookup, const uint64_t* k_mont, const uint64_t* ch,
+                                          void* d_quot, jfhip_stream* stream) {
+    JF_TRY(check_curve(curve_id));
+    if (num_wire_types != 5 && num_wire_types != 6) {
+        set_error("quotient: %u wire types (5 = TurboPlonk, 6 = UltraPlonk)", num_wire_types);
+        return JFHIP_ERR_INVALID;
+    }
+    if (!coset_offset_mont || !d_sel || !d_sig || !d_wires || !d_zperm || !d_pi || !k_mont || !ch || !d_quot ||
+        (num_wire_types == 6 && !d_plookup)) {
+        set_error("null argument");
+        return JFHIP_ERR_INVALID;
+    }
+    JF_STREAM(st, stream);
+    std::lock_guard<std::mutex> lk(st->mu);
+    return plonk_quotient_coset_device(curve_id, (int)num_wire_types, log_n, log_m, coset_offset_mont,
+                                       (const uint32_t*)d_sel, (const uint32_t*)d_sig, (const uint32_t*)d_wires,
+                                       (const uint32_t*)d_zperm, (const uint32_t*)d_pi, (const uint32_t*)d_plookup,
+                                       k_mont, ch, (uint32_t*)d_quot, st);
+}
+
 int32_t jfhip_plonk_perm_product_device(int32_t curve_id, uint32_t log_n, uint32_t num_wire_types,
                                         const void* d_wire_vals, const void* d_id_perm, const void* d_sigma_vals,
                                         const uint64_t* beta, const uint64_t* gamma, void* d_out,

@@ -50,7 +50,7 @@ struct jfhip_stream {
     bool owned = false;
     std::mutex mu;  // one MSM/NTT at a time per stream object (workspace is per stream)
     // MSM workspace
-    jf::DevBuf scalars, dig, dig2, sorted, counts, offs, cursor, bsum, midbase, midcnt, midcur, finecnt, finecur, buckets, partA, partB, red0, red1, result;
+    jf::DevBuf scalars, dig, dig2, sorted, counts, offs, cursor, bsum, midbase, midcnt, midcur, finecnt, finecur, buckets, partA, partB, red0, red1, result, raw29, heavy;
     // NTT workspace
     jf::DevBuf ntt_tmp, ntt_io;
     // open()
@@ -113,6 +113,11 @@ int32_t plonk_quotient_ultra_device(int32_t curve, uint32_t log_n, uint32_t log_
                                     const uint32_t* sig, const uint32_t* wires, const uint32_t* zperm,
                                     const uint32_t* pi, const uint32_t* lookup, const uint64_t* k_mont,
                                     const uint64_t* challenges_mont, uint32_t* out, jfhip_stream* st);
+int32_t plonk_quotient_coset_device(int32_t curve, int nw, uint32_t log_n, uint32_t log_m, const uint64_t* offset_mont,
+                                    const uint32_t* sel, const uint32_t* sig, const uint32_t* wires,
+                                    const uint32_t* zperm, const uint32_t* pi, const uint32_t* lookup,
+                                    const uint64_t* k_mont, const uint64_t* challenges_mont, uint32_t* out,
+                                    jfhip_stream* st);
 int32_t plonk_perm_product_device(int32_t curve, uint32_t log_n, uint32_t nw, const uint32_t* wires,
                                   const uint32_t* idp, const uint32_t* sig, const uint64_t* beta, const uint64_t* gamma,
                                   uint32_t* out, jfhip_stream* st);

@@ -401,6 +401,23 @@ JF_DEV XYZZ<Cv> xyzz29_to_std(const XYZZ29<Cv>& a, bool inf) {
     return r;
 }
 
+template <class Cv>
+JF_DEV void xyzz29_store_raw(uint32_t* __restrict__ dst, const XYZZ29<Cv>& a, bool inf) {
+    constexpr int L = F29<typename Cv::Fq>::L;
+    static_assert((4 * L) % 4 == 0, "");
+    uint32_t w[4 * L];
+#pragma unroll
+    for (int k = 0; k < L; k++) {
+        w[k] = inf ? 0u : a.X.v[k];
+        w[L + k] = inf ? 0u : a.Y.v[k];
+        w[2 * L + k] = inf ? 0u : a.ZZ.v[k];
+        w[3 * L + k] = inf ? 0u : a.ZZZ.v[k];
+    }
+#pragma unroll
+    for (int k = 0; k < L; k++)
+        reinterpret_cast<uint4*>(dst)[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
+}
+
 // rare path of the mixed add (P + P or P - P): fall back to the saturated formulas, out of line.  Everything goes
 // in and out BY VALUE: a reference would make the hot loop's accumulator escape into scratch memory.
 template <class Cv>
@@ -431,10 +448,14 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
                                                           const uint32_t* __restrict__ table, uint32_t L,
                                                           uint32_t* __restrict__ buckets, uint32_t* __restrict__ partA,
                                                           uint32_t* __restrict__ partB) {
+    // buckets / partA / partB are RAW here: 4 L29 words per element, lazily reduced 29-bit limbs, all zero = identity.
+    // Converting to the saturated form inside flush() would put ~1400 instructions on a branch that some lane of
+    // a wave takes in half of all iterations (average bucket ~ 96 entries, 64 lanes); k_xyzz29_to_std converts
+    // afterwards, one element per lane, fully convergent.
     using Q = typename Cv::Fq;
     using F = F29<Q>;
     constexpr int PT = 2 * Q::N;
-    constexpr int XZ = 4 * Q::N;
+    constexpr int XZ = 4 * F::L;
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t total = off[B];
     const uint64_t start64 = (uint64_t)t * L;
@@ -476,10 +497,17 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
             dst = partB + (size_t)t * XZ;
             wroteB = true;
         }
-        xyzz_store<Cv>(dst, xyzz29_to_std<Cv>(acc, inf));
+        xyzz29_store_raw<Cv>(dst, acc, inf);
     };
 
+    // software pipeline: the table point of entry pos + 1 (a random 64 / 96-byte gather from a multi-GiB table) and the
+    // sorted entry pos + 2 are in flight while entry pos is added
+    uint32_t e_cur = sorted[start];
+    uint32_t e_nxt = (start + 1 < end) ? sorted[start + 1] : e_cur;
+    Affine<Cv> p_cur = affine_load<Cv>(table + (size_t)(e_cur & 0x7fffffffu) * PT);
     for (uint32_t pos = start; pos < end; pos++) {
+        const Affine<Cv> p_nxt = affine_load<Cv>(table + (size_t)(e_nxt & 0x7fffffffu) * PT);
+        const uint32_t e_nx2 = (pos + 2 < end) ? sorted[pos + 2] : e_nxt;
         if (pos >= b_hi) {
             flush(pos);
             inf = true;
@@ -490,44 +518,76 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
                 b_hi = off[b + 1];
             } while (pos >= b_hi);
         }
-        const uint32_t e = sorted[pos];
-        const Affine<Cv> p = affine_load<Cv>(table + (size_t)(e & 0x7fffffffu) * PT);
-        if (p.is_inf()) continue;
-        F x2 = f29_unpack_bits<Q>(p.x);
-        F y2 = f29_unpack_bits<Q>(p.y);
-        if (e >> 31) y2 = f29_sub<Q, 1>(zero29, y2);   // p - y (y < p)
-        if (inf) {
-            acc.X = x2;
-            acc.Y = y2;
-            acc.ZZ = one29;
-            acc.ZZZ = one29;
-            inf = false;
-            continue;
-        }
-        F U2 = f29_mul<Q>(x2, acc.ZZ);
-        F S2 = f29_mul<Q>(y2, acc.ZZZ);
-        F P = f29_sub<Q, 8>(U2, acc.X);
-        F PP = f29_sqr<Q>(P);
-        if (f29_mulout_is_zero<Q>(PP)) {
-            XYZZ29<Cv> ac = acc;
-            Rare29<Cv> rr = xyzz29_add_rare<Cv>(ac, x2, y2);
-            acc = rr.acc;
-            inf = rr.inf;
-            continue;
-        }
-        F R = f29_sub<Q, 4>(S2, acc.Y);
-        F PPP = f29_mul<Q>(P, PP);
-        F Qv = f29_mul<Q>(acc.X, PP);
-        F X3 = f29_sub3<Q, 6>(f29_sqr<Q>(R), PPP, Qv, Qv);
-        F Y3 = f29_sub<Q, 2>(f29_mul<Q>(R, f29_sub<Q, 8>(Qv, X3)), f29_mul<Q>(acc.Y, PPP));
-        acc.X = X3;
-        acc.Y = Y3;
-        acc.ZZ = f29_mul<Q>(acc.ZZ, PP);
-        acc.ZZZ = f29_mul<Q>(acc.ZZZ, PPP);
+        do {
+            const uint32_t e = e_cur;
+            const Affine<Cv> p = p_cur;
+            if (p.is_inf()) break;
+            F x2 = f29_unpack_bits<Q>(p.x);
+            F y2 = f29_unpack_bits<Q>(p.y);
+            if (e >> 31) y2 = f29_sub<Q, 1>(zero29, y2);   // p - y (y < p)
+            if (inf) {
+                acc.X = x2;
+                acc.Y = y2;
+                acc.ZZ = one29;
+                acc.ZZZ = one29;
+                inf = false;
+                break;
+            }
+            F U2 = f29_mul<Q>(x2, acc.ZZ);
+            F S2 = f29_mul<Q>(y2, acc.ZZZ);
+            F P = f29_sub<Q, 8>(U2, acc.X);
+            F PP = f29_sqr<Q>(P);
+            if (f29_mulout_is_zero<Q>(PP)) {
+                XYZZ29<Cv> ac = acc;
+                Rare29<Cv> rr = xyzz29_add_rare<Cv>(ac, x2, y2);
+                acc = rr.acc;
+                inf = rr.inf;
+                break;
+            }
+            F R = f29_sub<Q, 4>(S2, acc.Y);
+            F PPP = f29_mul<Q>(P, PP);
+            F Qv = f29_mul<Q>(acc.X, PP);
+            F X3 = f29_sub3<Q, 6>(f29_sqr<Q>(R), PPP, Qv, Qv);
+            F Y3 = f29_sub<Q, 2>(f29_mul<Q>(R, f29_sub<Q, 8>(Qv, X3)), f29_mul<Q>(acc.Y, PPP));
+            acc.X = X3;
+            acc.Y = Y3;
+            acc.ZZ = f29_mul<Q>(acc.ZZ, PP);
+            acc.ZZZ = f29_mul<Q>(acc.ZZZ, PPP);
+        } while (0);
+        e_cur = e_nxt;
+        p_cur = p_nxt;
+        e_nxt = e_nx2;
     }
     flush(end);
-    if (!wroteA) xyzz_store<Cv>(partA + (size_t)t * XZ, XYZZ<Cv>::identity());
-    if (!wroteB) xyzz_store<Cv>(partB + (size_t)t * XZ, XYZZ<Cv>::identity());
+    if (!wroteA) xyzz29_store_raw<Cv>(partA + (size_t)t * XZ, acc, true);
+    if (!wroteB) xyzz29_store_raw<Cv>(partB + (size_t)t * XZ, acc, true);
+}
+
+// raw (4 L29 words, lazily reduced) -> saturated XYZZ, one element per lane: elements [0, B) are buckets,
+// [B, B + T) the slices' leading partial runs, [B + T, B + 2T) the trailing ones
+template <class Cv>
+__global__ __launch_bounds__(256) void k_xyzz29_to_std(const uint32_t* __restrict__ raw, uint32_t B, uint32_t T,
+                                                       uint32_t* __restrict__ buckets, uint32_t* __restrict__ partA,
+                                                       uint32_t* __restrict__ partB) {
+    using Q = typename Cv::Fq;
+    using F = F29<Q>;
+    constexpr int XZ = 4 * Q::N;
+    constexpr int XR = 4 * F::L;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B + 2 * (size_t)T) return;
+    const uint32_t* src = raw + i * XR;
+    XYZZ29<Cv> a;
+    uint32_t nz = 0;
+#pragma unroll
+    for (int k = 0; k < F::L; k++) {
+        a.X.v[k] = src[k];
+        a.Y.v[k] = src[F::L + k];
+        a.ZZ.v[k] = src[2 * F::L + k];
+        a.ZZZ.v[k] = src[3 * F::L + k];
+        nz |= a.ZZ.v[k];
+    }
+    uint32_t* dst = i < B ? buckets + i * XZ : (i < (size_t)B + T ? partA + (i - B) * XZ : partB + (i - B - T) * XZ);
+    xyzz_store<Cv>(dst, xyzz29_to_std<Cv>(a, nz == 0));
 }
 
 // table entries x -> x 2^(+-SHIFT): saturated Montgomery factor R <-> R' (identity entries (0, 0) are unchanged)
@@ -550,12 +610,15 @@ int32_t table_rescale(int32_t curve, uint32_t* d_pts, size_t count, int up, hipS
     return JFHIP_OK;
 }
 
-// buckets spanning >= 2 slices: sum their pieces
+// buckets spanning >= 2 slices: sum their pieces.  One lane per bucket; a bucket spanning more than HEAVY_SPAN slices
+// (skewed scalars: all-equal scalars put n entries into one bucket per window = 65536 slices at 2^24, 0.8 s of serial
+// additions on one lane) is queued for k_msm_fixup_heavy instead.
+constexpr uint32_t HEAVY_SPAN = 48;
 template <class Cv>
 __global__ __launch_bounds__(128) void k_msm_fixup(const uint32_t* __restrict__ off, uint32_t B, uint32_t L,
                                                    const uint32_t* __restrict__ partA,
                                                    const uint32_t* __restrict__ partB,
-                                                   uint32_t* __restrict__ buckets) {
+                                                   uint32_t* __restrict__ buckets, uint32_t* __restrict__ heavy) {
     constexpr int XZ = 4 * Cv::Fq::N;
     uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
@@ -563,12 +626,50 @@ __global__ __launch_bounds__(128) void k_msm_fixup(const uint32_t* __restrict__ 
     if (e <= s) return;
     uint32_t t1 = s / L, t2 = (e - 1) / L;
     if (t1 == t2) return;
+    if (t2 - t1 > HEAVY_SPAN) {
+        heavy[1 + atomicAdd(heavy, 1u)] = b;
+        return;
+    }
     XYZZ<Cv> acc = xyzz_load<Cv>(((s % L == 0) ? partA : partB) + (size_t)t1 * XZ);
     for (uint32_t t = t1 + 1; t <= t2; t++) {
         XYZZ<Cv> q = xyzz_load<Cv>(partA + (size_t)t * XZ);
         xyzz_add_inl<Cv>(acc, q);
     }
     xyzz_store<Cv>(buckets + (size_t)b * XZ, acc);
+}
+
+// one workgroup per queued bucket: lanes take the bucket's slices round-robin, then an LDS tree
+template <class Cv>
+__global__ __launch_bounds__(256) void k_msm_fixup_heavy(const uint32_t* __restrict__ off, uint32_t L,
+                                                         const uint32_t* __restrict__ partA,
+                                                         const uint32_t* __restrict__ partB,
+                                                         uint32_t* __restrict__ buckets,
+                                                         const uint32_t* __restrict__ heavy) {
+    constexpr int XZ = 4 * Cv::Fq::N;
+    __shared__ uint32_t sh[256 * XZ];
+    const uint32_t count = heavy[0];
+    for (uint32_t h = blockIdx.x; h < count; h += gridDim.x) {
+        const uint32_t b = heavy[1 + h];
+        const uint32_t s = off[b], e = off[b + 1];
+        const uint32_t t1 = s / L, t2 = (e - 1) / L;
+        XYZZ<Cv> acc = XYZZ<Cv>::identity();
+        if (threadIdx.x == 0) acc = xyzz_load<Cv>(((s % L == 0) ? partA : partB) + (size_t)t1 * XZ);
+        for (uint32_t t = t1 + 1 + threadIdx.x; t <= t2; t += 256u) {
+            XYZZ<Cv> q = xyzz_load<Cv>(partA + (size_t)t * XZ);
+            xyzz_add_inl<Cv>(acc, q);
+        }
+        xyzz_store<Cv>(sh + threadIdx.x * XZ, acc);
+        __syncthreads();
+        for (uint32_t w = 128; w > 0; w >>= 1) {
+            if (threadIdx.x < w) {
+                XYZZ<Cv> q = xyzz_load<Cv>(sh + (threadIdx.x + w) * XZ);
+                xyzz_add_inl<Cv>(acc, q);
+                xyzz_store<Cv>(sh + threadIdx.x * XZ, acc);
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) xyzz_store<Cv>(buckets + (size_t)b * XZ, acc);
+    }
 }
 
 // k * p for a small non-negative integer k (double-and-add, MSB first)
@@ -1061,16 +1162,27 @@ static int32_t msm_partial_t(const jfhip_srs* srs, size_t offset, const uint32_t
     if (srs->f29) {
         static const int occ = [] { const char* e = getenv("JFHIP_MSM_F29_OCC"); return e ? atoi(e) : 4; }();
         auto kern = occ == 2 ? k_msm_accumulate29<Cv, 2> : occ == 3 ? k_msm_accumulate29<Cv, 3> : k_msm_accumulate29<Cv, 4>;
+        constexpr size_t XR = 4 * F29<typename Cv::Fq>::L;
+        const size_t elems = (size_t)B + 2 * T;
+        JF_TRY(st->raw29.ensure(elems * XR * 4));
+        uint32_t* raw = st->raw29.as<uint32_t>();
+        JF_HIP(hipMemsetAsync(raw, 0, (size_t)B * XR * 4, st->s));  // untouched buckets are the identity
         hipLaunchKernelGGL(kern, dim3((unsigned)((T + 127) / 128)), dim3(128), 0, st->s,
-                           st->sorted.as<uint32_t>(), offs, B, srs->table, (uint32_t)L, buckets,
-                           st->partA.as<uint32_t>(), st->partB.as<uint32_t>());
+                           st->sorted.as<uint32_t>(), offs, B, srs->table, (uint32_t)L, raw, raw + (size_t)B * XR,
+                           raw + ((size_t)B + T) * XR);
+        hipLaunchKernelGGL((k_xyzz29_to_std<Cv>), dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, st->s, raw, B,
+                           (uint32_t)T, buckets, st->partA.as<uint32_t>(), st->partB.as<uint32_t>());
     } else
         hipLaunchKernelGGL((k_msm_accumulate<Cv>), dim3((unsigned)((T + 127) / 128)), dim3(128), 0, st->s,
                            st->sorted.as<uint32_t>(), offs, B, srs->table, (uint32_t)L, buckets,
                            st->partA.as<uint32_t>(), st->partB.as<uint32_t>());
     pt.mark();
+    JF_TRY(st->heavy.ensure((T / HEAVY_SPAN + 4) * 4));
+    JF_HIP(hipMemsetAsync(st->heavy.p, 0, 4, st->s));
     hipLaunchKernelGGL((k_msm_fixup<Cv>), dim3((B + 127) / 128), dim3(128), 0, st->s, offs, B, (uint32_t)L,
-                       st->partA.as<uint32_t>(), st->partB.as<uint32_t>(), buckets);
+                       st->partA.as<uint32_t>(), st->partB.as<uint32_t>(), buckets, st->heavy.as<uint32_t>());
+    hipLaunchKernelGGL((k_msm_fixup_heavy<Cv>), dim3(1024), dim3(256), 0, st->s, offs, (uint32_t)L,
+                       st->partA.as<uint32_t>(), st->partB.as<uint32_t>(), buckets, st->heavy.as<uint32_t>());
     pt.mark();
     DevBuf& fold = st->partA;  // partA is free again after the fix-up
     hipLaunchKernelGGL((k_msm_bucket_fold<Cv>), dim3((Tf + 63) / 64), dim3(64), 0, st->s, buckets, B, g,

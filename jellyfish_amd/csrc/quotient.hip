@@ -27,6 +27,7 @@ struct QuotDomain {
 struct QuotKey {
     int device, curve;
     uint32_t log_n, log_m;
+    uint32_t offset[8];  // coset offset (Montgomery limbs); all zero = Fr::GENERATOR
     bool operator<(const QuotKey& o) const { return memcmp(this, &o, sizeof(QuotKey)) < 0; }
 };
 static std::mutex g_q_mu;
@@ -47,17 +48,33 @@ JF_DEV Fp<Fr> fp_from_small(uint32_t v) {
     return fp_to_mont<Fr>(t);
 }
 
+// coset offset of the evaluation domain as a kernel argument: Fr::GENERATOR (gen != 0) or an arbitrary element
+// (a rank's slice h w_m^g of the quotient coset, see jfhip_plonk_quotient_coset_device)
+struct CosetOffset {
+    uint32_t gen;
+    uint32_t v[8];
+};
+template <class Fr>
+JF_DEV Fp<Fr> coset_offset(const CosetOffset& o) {
+    static_assert(Fr::N == 8, "scalar fields have 8 limbs");
+    if (o.gen) return fp_from_small<Fr>(o.gen);
+    Fp<Fr> x;
+#pragma unroll
+    for (int i = 0; i < 8; i++) x.v[i] = o.v[i];
+    return x;
+}
+
 constexpr int INV_CHUNK = 8;
 // inv_den[i] = 1 / (n (g w^i - 1)): each lane inverts INV_CHUNK consecutive values with one inversion
 template <class Fr>
 __global__ __launch_bounds__(128) void k_quot_inv_den(const uint32_t* __restrict__ lo, const uint32_t* __restrict__ hi,
-                                                      uint32_t a, uint32_t log_n, uint32_t log_m, uint32_t gen,
+                                                      uint32_t a, uint32_t log_n, uint32_t log_m, CosetOffset gen,
                                                       uint32_t* __restrict__ inv_den) {
     constexpr int N = Fr::N;
     const uint64_t m = 1ull << log_m;
     uint64_t i0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * INV_CHUNK;
     if (i0 >= m) return;
-    const Fp<Fr> g = fp_from_small<Fr>(gen);
+    const Fp<Fr> g = coset_offset<Fr>(gen);
     const Fp<Fr> one = Fp<Fr>::one();
     // n in Montgomery form: 2^log_n
     Fp<Fr> nn = one;
@@ -83,10 +100,10 @@ __global__ __launch_bounds__(128) void k_quot_inv_den(const uint32_t* __restrict
 // z_h_inv[i] = 1 / ((g w^i)^n - 1), i < ratio   (prover.rs:509-516)
 template <class Fr>
 __global__ void k_quot_zh_inv(const uint32_t* __restrict__ lo, const uint32_t* __restrict__ hi, uint32_t a,
-                              uint32_t log_n, uint32_t ratio, uint32_t gen, uint32_t* __restrict__ zh_inv) {
+                              uint32_t log_n, uint32_t ratio, CosetOffset gen, uint32_t* __restrict__ zh_inv) {
     uint32_t i = threadIdx.x;
     if (i >= ratio || blockIdx.x) return;
-    Fp<Fr> x = fp_mul<Fr>(fp_from_small<Fr>(gen), root_pow<Fr>(lo, hi, a, i));
+    Fp<Fr> x = fp_mul<Fr>(coset_offset<Fr>(gen), root_pow<Fr>(lo, hi, a, i));
     for (uint32_t k = 0; k < log_n; k++) x = fp_sqr<Fr>(x);
     x = fp_sub<Fr>(x, Fp<Fr>::one());
     fp_store<Fr>(zh_inv + (size_t)i * Fr::N, fp_inv_binary<Fr>(x));
@@ -101,7 +118,7 @@ enum {
 constexpr int QUOT_NIN = 11;
 
 template <class Fr>
-__global__ void k_quot_consts(const uint32_t* __restrict__ in, uint32_t gen, const uint32_t* __restrict__ lo,
+__global__ void k_quot_consts(const uint32_t* __restrict__ in, CosetOffset gen, const uint32_t* __restrict__ lo,
                               const uint32_t* __restrict__ hi, uint32_t a, uint32_t log_n, uint32_t log_m,
                               uint32_t* __restrict__ out) {
     constexpr int N = Fr::N;
@@ -115,7 +132,7 @@ __global__ void k_quot_consts(const uint32_t* __restrict__ in, uint32_t gen, con
     fp_store<Fr>(out + QC_GAMMA * N, gamma);
     fp_store<Fr>(out + QC_ABASE * N, fp_load<Fr>(in + 10 * N));
     fp_store<Fr>(out + QC_ONE * N, Fp<Fr>::one());
-    fp_store<Fr>(out + QC_GEN * N, fp_from_small<Fr>(gen));
+    fp_store<Fr>(out + QC_GEN * N, coset_offset<Fr>(gen));
     fp_store<Fr>(out + QC_TAU * N, fp_load<Fr>(in + 9 * N));
     fp_store<Fr>(out + QC_ALPHA3 * N, a3);
     fp_store<Fr>(out + QC_ALPHA4 * N, a4);
@@ -233,9 +250,12 @@ template <class Fr>
 static int32_t quotient_t(int32_t curve, int nw, uint32_t log_n, uint32_t log_m, const uint32_t* sel,
                           const uint32_t* sig, const uint32_t* wires, const uint32_t* zperm, const uint32_t* pi,
                           const uint32_t* lookup, const uint64_t* k_mont, const uint64_t* ch, uint32_t* out,
-                          jfhip_stream* st) {
+                          jfhip_stream* st, const uint64_t* offset_mont = nullptr) {
     constexpr int N = Fr::N;
-    const uint32_t gen = curve == JFHIP_BN254 ? 5u : 7u;  // Fr::GENERATOR
+    CosetOffset gen;
+    memset(&gen, 0, sizeof(gen));
+    if (offset_mont) memcpy(gen.v, offset_mont, 32);
+    else gen.gen = curve == JFHIP_BN254 ? 5u : 7u;  // Fr::GENERATOR
     if (log_m < log_n || log_m > 30) {
         set_error("quotient: bad domain sizes (log_n %u, log_m %u)", log_n, log_m);
         return JFHIP_ERR_INVALID;
@@ -257,6 +277,7 @@ static int32_t quotient_t(int32_t curve, int nw, uint32_t log_n, uint32_t log_m,
         key.curve = curve;
         key.log_n = log_n;
         key.log_m = log_m;
+        memcpy(key.offset, gen.v, 32);
         std::lock_guard<std::mutex> lk(g_q_mu);
         auto it = g_qdom.find(key);
         if (it == g_qdom.end()) {
@@ -308,6 +329,18 @@ int32_t plonk_quotient_turbo_device(int32_t curve, uint32_t log_n, uint32_t log_
                                    out, st);
     return quotient_t<Bls381Fr>(curve, 5, log_n, log_m, sel, sig, wires, zperm, pi, nullptr, k_mont, challenges_mont, out,
                                 st);
+}
+
+int32_t plonk_quotient_coset_device(int32_t curve, int nw, uint32_t log_n, uint32_t log_m, const uint64_t* offset_mont,
+                                    const uint32_t* sel, const uint32_t* sig, const uint32_t* wires,
+                                    const uint32_t* zperm, const uint32_t* pi, const uint32_t* lookup,
+                                    const uint64_t* k_mont, const uint64_t* challenges_mont, uint32_t* out,
+                                    jfhip_stream* st) {
+    if (curve == JFHIP_BN254)
+        return quotient_t<Bn254Fr>(curve, nw, log_n, log_m, sel, sig, wires, zperm, pi, lookup, k_mont, challenges_mont,
+                                   out, st, offset_mont);
+    return quotient_t<Bls381Fr>(curve, nw, log_n, log_m, sel, sig, wires, zperm, pi, lookup, k_mont, challenges_mont, out,
+                                st, offset_mont);
 }
 
 int32_t plonk_quotient_ultra_device(int32_t curve, uint32_t log_n, uint32_t log_m, const uint32_t* sel,

@@ -287,6 +287,7 @@ class ProvingKey:
     # The reference recomputes these 18 coset FFTs in every proof (prover.rs:534-544); they depend on the proving key
     # only, and 288 GB of HBM holds them (18 x 256 MiB at n = 2^20).  Same values, so the same proof bytes.
     coset_evals: torch.Tensor = field(repr=False, default=None)
+    coset_slice: tuple = (0, 1)   # (rank, world) the resident evaluations were computed for
 
     def domain_size(self) -> int:
         return self.vk.domain_size
@@ -298,18 +299,23 @@ class ProvingKey:
             m <<= 1
         return m
 
-    def keep_coset_evals(self, stream=None) -> "ProvingKey":
-        """evaluate selectors and sigmas on the quotient coset once and keep them resident (see coset_evals)"""
+    def keep_coset_evals(self, stream=None, rank: int = 0, world: int = 1) -> "ProvingKey":
+        """evaluate selectors and sigmas on the quotient coset once and keep them resident (see coset_evals).
+        world > 1: only rank's slice of the coset (prove(sharded=True) with coset sharding, see quotient_slices)"""
         cp = H.CURVES[self.curve]
         n, m = self.vk.domain_size, self.quot_domain_size()
+        if not coset_sharding_applies(n, m, world):
+            rank, world = 0, 1
+        ml = m // world
         nsel, W = self.selectors.shape[0], self.sigmas.shape[0]
-        ev = torch.empty(nsel + W, m * 4, dtype=torch.int64, device="cuda")
+        ev = torch.empty(nsel + W, ml * 4, dtype=torch.int64, device="cuda")
         ev[:nsel, :n * 4].copy_(self.selectors)
         ev[nsel:, :n * 4].copy_(self.sigmas)
-        gen = H.fr_to_mont(cp, [cp.fr_generator])[0]
-        L.ntt_device(self.curve, ev.data_ptr(), m.bit_length() - 1, nsel + W, inverse=False, coset_mont=gen, in_len=n,
+        off = H.fr_to_mont(cp, [slice_offset(cp, m, rank)])[0]
+        L.ntt_device(self.curve, ev.data_ptr(), ml.bit_length() - 1, nsel + W, inverse=False, coset_mont=off, in_len=n,
                      stream=_stream(stream))
         self.coset_evals = ev
+        self.coset_slice = (rank, world)
         return self
 
 
@@ -454,6 +460,41 @@ def domain_size_ratio(n: int, num_wire_types: int) -> int:
     return (num_wire_types * (n + 1) + 2) // n + 1
 
 
+def coset_sharding_applies(n: int, m: int, world: int) -> bool:
+    """the quotient coset splits over `world` ranks when world divides m / n (8 for Turbo/UltraPlonk)"""
+    return world > 1 and (m // n) % world == 0 and n > 1
+
+
+def slice_offset(cp, m: int, rank: int) -> int:
+    """the points i = rank (mod G) of the quotient coset {h w_m^i} are the coset of size m / G with
+    offset h w_m^rank (h = Fr::GENERATOR, prover.rs:524-527)"""
+    w_m = pow(cp.two_adic_root, 1 << (cp.two_adicity - (m.bit_length() - 1)), cp.r)
+    return cp.fr_generator * pow(w_m, rank, cp.r) % cp.r
+
+
+def unshard_coeffs(cp, m: int, G: int) -> list:
+    """gathered[g] = t(X) mod (X^ml - c_g), c_g = h^ml w_G^g (rank g's coset iNTT of its slice of the quotient
+    evaluations), ml = m / G.  With t = sum_c X^(c ml) t_c:  gathered[g][j] = sum_c (h^ml)^c w_G^(g c) t_c[j], a size-G DFT
+    per coefficient index; its inverse  t_c = sum_g coeffs[c][g] * gathered[g],  coeffs[c][g] = h^(-ml c) w_G^(-g c) / G."""
+    r = cp.r
+    ml = m // G
+    w_m = pow(cp.two_adic_root, 1 << (cp.two_adicity - (m.bit_length() - 1)), r)
+    w_G_inv = pow(pow(w_m, ml, r), -1, r)
+    h_ml_inv = pow(pow(cp.fr_generator, ml, r), -1, r)
+    g_inv = pow(G, -1, r)
+    return [[pow(h_ml_inv, c, r) * g_inv % r * pow(w_G_inv, g * c, r) % r for g in range(G)] for c in range(G)]
+
+
+def unshard_quotient(cp, curve: int, gathered: torch.Tensor, m: int, out: torch.Tensor, stream):
+    """quotient coefficients from the G gathered slice polynomials (see unshard_coeffs): G lincombs of G terms"""
+    G = gathered.shape[0]
+    ml = m // G
+    ptrs = [gathered[g].data_ptr() for g in range(G)]
+    for c, coeffs in enumerate(unshard_coeffs(cp, m, G)):
+        L.poly_lincomb_device(curve, ptrs, [ml] * G, H.fr_to_mont(cp, coeffs), out.data_ptr() + c * ml * 32, ml,
+                              stream=stream)
+
+
 class PlonkKzgSnark:
     @staticmethod
     def universal_setup_for_testing(curve: int, max_degree: int, beta: int, g=None, h=None) -> UniversalSrs:
@@ -591,33 +632,76 @@ class PlonkKzgSnark:
         alpha = tr.get_challenge(b"alpha")
         NSEL = N_TURBO_PLONK_SELECTORS
         l4 = ln * 4
+        # coset sharding: rank g of G evaluates the slice i = g (mod G) of the quotient coset, a coset of
+        # size ml = m / G with offset h w_m^g; one all_gather of the slices' iNTTs rebuilds the quotient polynomial
+        G, g = 1, 0
+        if sharded:
+            import torch.distributed as tdist
+
+            G = tdist.get_world_size(group)
+            g = tdist.get_rank(group)
+            if not coset_sharding_applies(n, m, G):
+                G, g = 1, 0
+        ml = m // G
+        log_ml = ml.bit_length() - 1
+        off_int = slice_offset(cp, m, g)
+        off = mont([off_int])[0]
         if pk.coset_evals is not None:
             # selector / sigma coset evaluations are resident with the proving key: 7 transforms instead of 25
             fixed = pk.coset_evals
-            if fixed.shape != (NSEL + W, m * 4):
-                raise PlonkError("proving key coset evaluations have the wrong shape")
+            if fixed.shape != (NSEL + W, ml * 4) or pk.coset_slice != (g, G):
+                raise PlonkError("proving key coset evaluations were kept for another slice of the quotient coset")
             npolys, o_w = W + 2, 0
             sel_ptr, sig_ptr = fixed[0].data_ptr(), fixed[NSEL].data_ptr()
         else:
             npolys, o_w = NSEL + 2 * W + 2, NSEL + W
         o_z, o_pi = o_w + W, o_w + W + 1
-        cs = torch.empty(npolys, m * 4, dtype=torch.int64, device="cuda")
-        cs[:, n4:l4].zero_()
+        cs = torch.empty(npolys, ml * 4, dtype=torch.int64, device="cuda")
+        lc4 = min(l4, ml * 4)
+        cs[:, n4:lc4].zero_()
         if pk.coset_evals is None:
             cs[:NSEL, :n4].copy_(pk.selectors)
             cs[NSEL:o_w, :n4].copy_(pk.sigmas)
             sel_ptr, sig_ptr = cs[0].data_ptr(), cs[NSEL].data_ptr()
-        cs[o_w:o_z, :l4].copy_(wire_polys)
-        cs[o_z, :l4].copy_(perm_poly)
+        cs[o_w:o_z, :lc4].copy_(wire_polys[:, :lc4])
+        cs[o_z, :lc4].copy_(perm_poly[:lc4])
         cs[o_pi, :n4].copy_(pub_poly)
-        L.ntt_device(c, cs.data_ptr(), log_m, npolys, inverse=False, coset_mont=gen, in_len=ln, stream=st)
+        if lc4 < l4:
+            # ml = n < n + 3 coefficients: reduce mod X^ml - off^ml (the slice's vanishing polynomial)
+            fold = mont([1, pow(off_int, ml, r)])
+            k = (l4 - lc4) // 4
+            tmp = torch.empty(W + 1, k * 4, dtype=torch.int64, device="cuda")
+            for j, poly in enumerate([wire_polys[j] for j in range(W)] + [perm_poly]):
+                L.poly_lincomb_device(c, [poly.data_ptr(), poly.data_ptr() + lc4 * 8], [k, k], fold, tmp[j].data_ptr(), k,
+                                      stream=st)
+            cs[o_w:o_z + 1, :k * 4].copy_(tmp)
+        L.ntt_device(c, cs.data_ptr(), log_ml, npolys, inverse=False, coset_mont=off, in_len=lc4 // 4, stream=st)
         tick("r3_coset_ntts")
         quot = torch.zeros(m * 4, dtype=torch.int64, device="cuda")
-        L.plonk_quotient_turbo_device(c, log_n, log_m, sel_ptr, sig_ptr, cs[o_w].data_ptr(),
-                                      cs[o_z].data_ptr(), cs[o_pi].data_ptr(), mont(vk.k), mont([alpha, beta, gamma, 1]),
-                                      quot.data_ptr(), stream=st)
-        del cs
-        L.ntt_device(c, quot.data_ptr(), log_m, 1, inverse=True, coset_mont=gen, stream=st)
+        if G == 1:
+            L.plonk_quotient_turbo_device(c, log_n, log_m, sel_ptr, sig_ptr, cs[o_w].data_ptr(),
+                                          cs[o_z].data_ptr(), cs[o_pi].data_ptr(), mont(vk.k),
+                                          mont([alpha, beta, gamma, 1]), quot.data_ptr(), stream=st)
+            del cs
+            L.ntt_device(c, quot.data_ptr(), log_m, 1, inverse=True, coset_mont=gen, stream=st)
+        else:
+            part = torch.zeros(ml * 4, dtype=torch.int64, device="cuda")
+            L.plonk_quotient_coset_device(c, W, log_n, log_ml, off, sel_ptr, sig_ptr, cs[o_w].data_ptr(),
+                                          cs[o_z].data_ptr(), cs[o_pi].data_ptr(), 0, mont(vk.k),
+                                          mont([alpha, beta, gamma, 1]), part.data_ptr(), stream=st)
+            del cs
+            L.ntt_device(c, part.data_ptr(), log_ml, 1, inverse=True, coset_mont=off, stream=st)
+            st.sync()
+            if tdist.get_backend(group) == "gloo":
+                host = torch.empty(G * ml * 4, dtype=torch.int64)
+                tdist.all_gather_into_tensor(host, part.cpu(), group=group)
+                gathered = host.cuda().view(G, ml * 4)
+            else:
+                gathered = torch.empty(G * ml * 4, dtype=torch.int64, device="cuda")
+                tdist.all_gather_into_tensor(gathered, part, group=group)
+                torch.cuda.current_stream().synchronize()
+                gathered = gathered.view(G, ml * 4)
+            unshard_quotient(cp, c, gathered, m, quot, st)
         tick("r3_quotient_intt")
         expected_degree = W * (n + 1) + 2
         tail_nonzero = bool(torch.any(quot[(expected_degree + 1) * 4:] != 0).item())

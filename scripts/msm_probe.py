@@ -11,7 +11,10 @@ for logn in [int(x) for x in sys.argv[1:]] or [24]:
     n = 1 << logn
     beta = bench.uniform_fr(1, 1, bench.BN254_R)[0]
     srs = L.Srs.gen_for_testing(0, beta, bench.BN254_G, n)
-    sc = torch.from_numpy(bench.uniform_fr(n, 2, bench.BN254_R).view(np.int64)).cuda()
+    sc_np = bench.uniform_fr(n, 2, bench.BN254_R)
+    if os.environ.get("JF_PROBE_SCALARS") == "same":     # one bucket per window, table read in index order
+        sc_np[:] = sc_np[0]
+    sc = torch.from_numpy(sc_np.view(np.int64)).cuda()
     out = torch.zeros(128, dtype=torch.uint8, device="cuda")
     st = L.Stream()
     for _ in range(3):

@@ -48,6 +48,15 @@ def _worker(rank, world, port, n, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        _worker_body(rank, world, n, q)
+    except Exception as e:  # report instead of leaving the parent waiting
+        q.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _worker_body(rank, world, n, q):
     from oracle import coracle as C
     from oracle import pyref as R
     from tests.util import mont_arr, pt_arr, rand_fr_mont
@@ -73,8 +82,55 @@ def _worker(rank, world, port, n, q):
     gathered = [None] * world
     dist.all_gather_object(gathered, mine)
     ok = ok and sorted(sum(gathered, [])) == list(range(11))
-    q.put((rank, ok))
-    dist.destroy_process_group()
+    # coset sharding of the quotient: this rank evaluates its slice of the coset, inverts the slice
+    # transform, ONE all_gather, then the size-G DFT inverse per coefficient rebuilds the polynomial on every rank
+    ok = ok and _coset_sharding_roundtrip(cv, 3, 6, world, rank, gather=True)
+    q.put((rank, bool(ok)))
+
+
+def _coset_sharding_roundtrip(cv, log_n, log_m, G, rank=None, gather=False):
+    """t (degree < m) -> per-slice evaluations on {h w_m^(g + G j)} -> slice iNTT -> unshard_coeffs -> t"""
+    from jellyfish_amd import hostglue as H
+    from jellyfish_amd import plonk as JP
+    from oracle import pyref as R
+
+    cp = H.CURVES[cv.curve_id]
+    r, m = cv.fr.p, 1 << log_m
+    ml = m // G
+    rng = R.SplitMix64(77 + G)
+    t = [rng.field(cv.fr) for _ in range(m)]
+    whole = R.fft(cv, t, log_m, cv.fr_generator)
+    assert JP.coset_sharding_applies(1 << log_n, m, G)
+
+    def slice_poly(g):
+        off = JP.slice_offset(cp, m, g)
+        # the slice of the whole coset IS the size-ml coset with this offset (of t reduced mod X^ml - off^ml)
+        c = pow(off, ml, r)
+        folded = [sum(t[k * ml + j] * pow(c, k, r) for k in range(G)) % r for j in range(ml)]
+        assert R.fft(cv, folded, ml.bit_length() - 1, off) == whole[g::G]
+        return R.ifft(cv, whole[g::G], ml.bit_length() - 1, off)
+
+    if gather:
+        mine = torch.tensor([[x >> (52 * k) & (2**52 - 1) for k in range(5)] for x in slice_poly(rank)], dtype=torch.int64)
+        out = torch.empty(G * ml, 5, dtype=torch.int64)
+        dist.all_gather_into_tensor(out, mine)
+        out = out.view(G, ml, 5)
+        polys = [[sum(int(w) << (52 * k) for k, w in enumerate(row)) for row in out[g].tolist()] for g in range(G)]
+    else:
+        polys = [slice_poly(g) for g in range(G)]
+    coeffs = JP.unshard_coeffs(cp, m, G)
+    back = []
+    for c in range(G):
+        back += [sum(coeffs[c][g] * polys[g][j] for g in range(G)) % r for j in range(ml)]
+    return back == t
+
+
+@pytest.mark.parametrize("G", [2, 4, 8])
+def test_coset_sharding_algebra(G):
+    from oracle import pyref as R
+
+    for cv in (R.BN254, R.BLS12_381):
+        assert _coset_sharding_roundtrip(cv, 2, 5, G)
 
 
 def test_shard_range_partitions():
@@ -99,4 +155,4 @@ def test_sharded_msm_world2_gloo():
     results = [q.get(timeout=240) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
-    assert all(ok for _, ok in results), results
+    assert all(ok is True for _, ok in results), results

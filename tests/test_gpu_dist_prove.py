@@ -127,7 +127,7 @@ def test_batch_prove_one_circuit_per_rank_aggregates_by_group_sum():
             assert (agg[j][:96].view(np.uint64) == C.ec_add(1, a, b)).all(), j
 
 
-def _real_worker(rank, world, port, q):
+def _real_worker(rank, world, port, q, size=300):
     import torch
     import torch.distributed as dist
 
@@ -142,30 +142,37 @@ def _real_worker(rank, world, port, q):
         torch.cuda.set_device(0)
         L.load_library()
         L.init(0)
-        cs = build(JP.PlonkCircuit(0), 300)
+        cs = build(JP.PlonkCircuit(0), size)
         srs = JP.PlonkKzgSnark.universal_setup_for_testing(0, cs.eval_domain_size() + 2, BETA)
         pk, _ = JP.PlonkKzgSnark.preprocess(srs, cs)
         ref = JP.PlonkKzgSnark.prove(JP.H.test_rng(), cs, pk).serialize_compressed()
         got = JP.PlonkKzgSnark.prove(JP.H.test_rng(), cs, pk, sharded=True).serialize_compressed()
-        q.put((rank, ref == got))
+        # the proving key keeps this rank's slice of the selector / sigma coset evaluations
+        pk.keep_coset_evals(rank=rank, world=world)
+        kept = JP.PlonkKzgSnark.prove(JP.H.test_rng(), cs, pk, sharded=True).serialize_compressed()
+        q.put((rank, ref == got and ref == kept))
     except Exception as e:
         q.put((rank, repr(e)))
     finally:
         dist.destroy_process_group()
 
 
-def test_two_rank_sharded_real_prove_is_byte_identical():
-    """PlonkKzgSnark.prove(sharded=True) with two ranks sharing cuda:0: commitment point ranges split over the ranks,
-    one all_gather per commit round; the proof bytes equal the single-device proof."""
+@pytest.mark.parametrize("world,size", [(2, 300), (4, 40), (8, 100)])
+def test_sharded_real_prove_is_byte_identical(world, size):
+    """PlonkKzgSnark.prove(sharded=True) with 2 / 4 / 8 ranks sharing cuda:0 (BASELINE config 4 layout): commitment point
+    ranges split over the ranks (one all_gather per commit round) and the quotient coset split into one slice per rank
+    (SURVEY.md 8e: slice-local coset NTTs and quotient evaluation, one all_gather of the slices' inverse transforms;
+    world 8 = m / n exercises the fold of the n + 3 coefficients mod X^n - c).  Proof bytes equal the single-device
+    proof, with and without the proving key's resident coset evaluations."""
     import torch.multiprocessing as mp
 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_real_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_real_worker, args=(r, world, port, q, size)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=150) for _ in procs]
+    res = [q.get(timeout=200) for _ in procs]
     for p in procs:
         p.join(timeout=30)
-    assert sorted(res) == [(0, True), (1, True)], res
+    assert sorted(res) == [(r, True) for r in range(world)], res

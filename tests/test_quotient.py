@@ -233,3 +233,41 @@ def test_ultra_quotient_gpu_matches_oracle(hip, cv, log_n, log_m):
     exp = C.plonk_quotient_ultra(*args, out=C.plonk_quotient_ultra(*args))
     assert (got == exp).all()
     st.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cv", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("ultra", [False, True], ids=["turbo", "ultra"])
+@pytest.mark.parametrize("log_n,log_m,G", [(2, 5, 2), (6, 9, 4), (6, 9, 8), (10, 13, 8)])
+def test_quotient_coset_slices_gpu_match_oracle(hip, cv, ultra, log_n, log_m, G):
+    """SURVEY.md 8e coset sharding: rank g of G evaluates the points i = g (mod G) of the quotient coset as the coset of
+    size m / G with offset h w_m^g (jfhip_plonk_quotient_coset_device); the G slices together are the oracle's evaluation
+    of the whole coset, bit for bit (G = 8 = m / n: one point of every Z_H class per slice, "next" = index + 1)."""
+    import torch
+
+    inst = (random_ultra_instance if ultra else random_instance)(cv, log_n, log_m, 1300 + log_n + G)
+    m = 1 << log_m
+    if ultra:
+        exp = C.plonk_quotient_ultra(cv.curve_id, log_n, log_m, inst["sel"], inst["sig"], inst["wires"], inst["zperm"],
+                                     inst["pi"], inst["lookup"], inst["k"], *inst["ch"])
+    else:
+        exp = C.plonk_quotient_turbo(cv.curve_id, log_n, log_m, inst["sel"], inst["sig"], inst["wires"], inst["zperm"],
+                                     inst["pi"], inst["k"], *inst["ch"])
+    r = cv.fr.p
+    w_m = R.domain_root(cv, log_m)
+    st = hip.Stream()
+    ml = m // G
+    for g in range(G):
+        sl = lambda a: torch.from_numpy(np.ascontiguousarray(a[..., g::G, :]).view(np.int64)).cuda()
+        dev = {k: sl(np.asarray(inst[k])) for k in ("sel", "sig", "wires", "zperm", "pi") + (("lookup",) if ultra else ())}
+        quot = torch.zeros(ml * 4, dtype=torch.int64, device="cuda")
+        off = mont_arr(cv.fr, [cv.fr_generator * pow(w_m, g, r) % r])[0]
+        hip.plonk_quotient_coset_device(cv.curve_id, 6 if ultra else 5, log_n, ml.bit_length() - 1, off,
+                                        dev["sel"].data_ptr(), dev["sig"].data_ptr(), dev["wires"].data_ptr(),
+                                        dev["zperm"].data_ptr(), dev["pi"].data_ptr(),
+                                        dev["lookup"].data_ptr() if ultra else 0, inst["k"], inst["ch"], quot.data_ptr(),
+                                        stream=st)
+        st.sync()
+        got = quot.cpu().numpy().view(np.uint64).reshape(ml, 4)
+        assert (got == np.asarray(exp)[g::G]).all(), g
+    st.close()
