@@ -948,10 +948,15 @@ static int32_t srs_build_table_t(jfhip_srs* srs, jfhip_stream* st) {
     return JFHIP_OK;
 }
 
-// JFHIP_MSM_F29=0 keeps the table and the accumulation on saturated limbs (A/B measurements)
-static bool env_f29() {
+// Which arithmetic the bucket accumulation of an SRS uses.  Measured on MI355X (BN254, uniform scalars): the 29-bit-limb
+// kernel is 17 % faster at 2^20 points (1.33 vs 1.60 ms) and 13 % slower at 2^24 (20.7 vs 18.3 ms; 12 GiB table, 49 % of
+// a wave's iterations cross a bucket boundary), so the default takes it up to 2^21 points.
+// JFHIP_MSM_F29=0 / 1 forces saturated / 29-bit limbs (A/B measurements).
+static bool use_f29(size_t n) {
     const char* e = getenv("JFHIP_MSM_F29");
-    return !(e && e[0] == '0');
+    if (e && e[0] == '0') return false;
+    if (e && e[0] == '1') return true;
+    return n <= ((size_t)1 << 21);
 }
 
 int32_t srs_build_table(jfhip_srs* srs, const uint32_t* d_points_packed, jfhip_stream* st) {
@@ -960,7 +965,7 @@ int32_t srs_build_table(jfhip_srs* srs, const uint32_t* d_points_packed, jfhip_s
         JF_HIP(hipMemcpyAsync(srs->table, d_points_packed, srs->n * PT * 4, hipMemcpyDeviceToDevice, st->s));
     int32_t rc = (srs->curve == JFHIP_BN254) ? srs_build_table_t<Bn254G1>(srs, st) : srs_build_table_t<Bls381G1>(srs, st);
     if (rc != JFHIP_OK) return rc;
-    if (env_f29()) {
+    if (use_f29(srs->n)) {
         // the whole table moves to the Montgomery factor of the 29-bit-limb arithmetic (fp29.hpp)
         JF_TRY(table_rescale(srs->curve, srs->table, (size_t)(srs->W > 0 ? srs->W : 1) * srs->n, 1, st->s));
         JF_HIP(hipStreamSynchronize(st->s));
@@ -1160,7 +1165,7 @@ static int32_t msm_partial_t(const jfhip_srs* srs, size_t offset, const uint32_t
     }
     pt.mark();
     if (srs->f29) {
-        static const int occ = [] { const char* e = getenv("JFHIP_MSM_F29_OCC"); return e ? atoi(e) : 4; }();
+        static const int occ = [] { const char* e = getenv("JFHIP_MSM_F29_OCC"); return e ? atoi(e) : 3; }();
         auto kern = occ == 2 ? k_msm_accumulate29<Cv, 2> : occ == 3 ? k_msm_accumulate29<Cv, 3> : k_msm_accumulate29<Cv, 4>;
         constexpr size_t XR = 4 * F29<typename Cv::Fq>::L;
         const size_t elems = (size_t)B + 2 * T;

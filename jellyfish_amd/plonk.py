@@ -13,8 +13,8 @@ coset NTTs, the quotient evaluation, the coset iNTT, quotient splitting, 13 comm
 linearisation and the two opening quotients.  Per proof 13 group elements and 10 field elements cross PCIe, plus the
 witness upload.  There is no CPU path: without libjfhip / a GPU every call raises.
 
-Checked against oracle/plonk_ref.py (byte-identical proofs from the same RNG stream; proofs verify) in
-tests/test_gpu_plonk.py.
+Checked against the big-integer restatement of prover and verifier (byte-identical proofs from the same RNG stream;
+proofs verify) in tests/test_gpu_plonk.py.
 """
 from __future__ import annotations
 
@@ -607,8 +607,12 @@ class PlonkKzgSnark:
         wire_polys = torch.zeros(W, ln * 4, dtype=torch.int64, device="cuda")
         wire_polys[:, :n4].copy_(buf[:W])
         pub_poly = buf[W]
-        for j in range(W):
-            mask(wire_polys[j], 1)
+        # mask_polynomial for the W wire polynomials with ONE read-back and two uploads (RNG draws in the reference's
+        # order: b_0, b_1 of wire 0, then wire 1, ...)
+        bs = [[H.fr_rand(cp, rng) for _ in range(2)] for _ in range(W)]
+        low = _read_fr(cp, wire_polys[:, :8].contiguous().view(-1))
+        wire_polys[:, :8] = _dev_fr(mont([(low[2 * j + i] - bs[j][i]) % r for j in range(W) for i in range(2)])).view(W, 8)
+        wire_polys[:, n4:n4 + 8] = _dev_fr(mont([b for row in bs for b in row])).view(W, 8)
         tick("r1_mask")
         wires_poly_comms = commit([wire_polys[j] for j in range(W)], [n + 2] * W)
         tr.append_commitments(b"witness_poly_comms", wires_poly_comms)
