@@ -385,6 +385,20 @@ def main():
                          "unit": "GB/s", "frac": round(alg_bytes / (acc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                          "measured_copy_GBs": round(copy_bw / 1e9, 1)},
         }
+        # second wall of this kernel: every mixed addition gathers one random 64-byte table point.  jfhip_probe(4, GiB)
+        # measures the device's random 64-byte gather rate over a table of the same size, nothing else running.
+        table_gib = max(1, int(round(windows * n * 64 / 2**30)))
+        try:
+            gather_peak = L.probe(4, table_gib)
+            gathers = float(windows) * n
+            out["roofline"]["gather_view"] = {
+                "bound": "random 64-byte gathers", "table_GiB": table_gib,
+                "achieved": round(gathers / (acc_ms * 1e-3) / 1e9, 3), "peak": round(gather_peak / 1e9, 3),
+                "unit": "G gathers/s", "frac": round(gathers / (acc_ms * 1e-3) / gather_peak, 4),
+                "peak_source": "gather-only micro-benchmark on this device over a %d GiB table (5.5e10/s at 1 GiB, "
+                               "1.35e10/s at 12 GiB measured: TLB / fabric reach, not HBM bandwidth)" % table_gib}
+        except Exception as e:  # reporting only
+            out["roofline"]["gather_view"] = {"error": repr(e)}
         out["phases_ms"] = phases
 
         if not args.no_ntt:

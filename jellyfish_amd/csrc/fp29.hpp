@@ -319,13 +319,13 @@ JF_HD Fp<C> f29_pack_bits(const F29<C>& a) {
     return r;
 }
 
-// lazily reduced (< 16 p, normalised) -> fully reduced < p, still in 29-bit limbs
-template <class C>
+// lazily reduced (< 2^ROUNDS p, normalised) -> fully reduced < p, still in 29-bit limbs
+template <class C, int ROUNDS = 4>
 JF_HD F29<C> f29_reduce_full(const F29<C>& a) {
     constexpr int L = F29<C>::L;
     F29<C> cur = f29_normalize<C>(a);
 #pragma unroll
-    for (int sh = 3; sh >= 0; sh--) {
+    for (int sh = ROUNDS - 1; sh >= 0; sh--) {
         // t = cur - (p << sh), limb-wise with signed borrow
         F29<C> t;
         int64_t borrow = 0;
@@ -347,9 +347,15 @@ JF_HD F29<C> f29_reduce_full(const F29<C>& a) {
     return cur;
 }
 
-// 29-bit Montgomery (x R', lazily reduced) -> saturated Montgomery (x R), fully reduced
+// 29-bit Montgomery (x R', lazily reduced) -> saturated Montgomery (x R), fully reduced: ONE product with the raw
+// bits of R mod p (x R' * R / R' = x R, output < p + a p / R' < 2 p) and one conditional subtraction
 template <class C>
 JF_HD Fp<C> f29_to_fp(const F29<C>& a) {
+    return f29_pack_bits<C>(f29_reduce_full<C, 1>(f29_mul<C>(a, f29_unpack_bits<C>(Fp<C>::one()))));
+}
+// the same by halvings (no product): reference form, kept for the field tests
+template <class C>
+JF_HD Fp<C> f29_to_fp_halvings(const F29<C>& a) {
     Fp<C> x = f29_pack_bits<C>(f29_reduce_full<C>(a));
     for (int k = 0; k < F29Params<C>::SHIFT; k++) {
         // x / 2 mod p

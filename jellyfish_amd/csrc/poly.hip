@@ -331,6 +331,28 @@ __global__ __launch_bounds__(256) void k_probe_copy(const uint4* __restrict__ in
     for (; i < n; i += stride) out[i] = in[i];
 }
 
+// random 64-byte gathers from a table of `npts` points, L per lane, at the bucket accumulation's occupancy (4 waves per
+// SIMD): DEP = 1 issues a lane's next gather only after the previous one returned (one in flight per lane, like the
+// accumulate loop without prefetch); DEP = 0 leaves them independent.
+template <int DEP>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_probe_gather(
+    const uint4* __restrict__ table, uint64_t npts, uint32_t L, uint32_t* __restrict__ out) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint4 acc = make_uint4(0, 0, 0, 0);
+    uint32_t h = t * 2654435761u + 12345u;
+    for (uint32_t k = 0; k < L; k++) {
+        h = h * 1664525u + 1013904223u + (DEP ? (acc.x & 1u) : 0u);
+        const uint64_t idx = ((uint64_t)(h ^ (h >> 15)) * npts) >> 32;
+        const uint4* p = table + idx * 4;
+        uint4 a = p[0], b = p[1], c = p[2], d = p[3];
+        acc.x ^= a.x ^ b.y ^ c.z ^ d.w;
+        acc.y += a.y + b.x;
+        acc.z ^= c.x + d.y;
+        acc.w += a.w ^ d.x;
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9e3779b9u) out[0] = acc.x;
+}
+
 template <class C>
 __global__ __launch_bounds__(256) void k_probe_mul29(uint32_t iters, uint32_t seed, uint32_t* __restrict__ out) {
     F29<C> x = f29_from_fp<C>(Fp<C>::one()), y = f29_from_fp<C>(Fp<C>::r2());
@@ -416,6 +438,24 @@ int32_t probe(int32_t kind, int32_t arg, double* out) {
         launch(iters);
         JF_HIP(hipEventRecord(e1, 0));
         work = (double)blocks * 256.0 * iters * 2.0;
+    } else if (kind == 4 || kind == 5) {
+        // arg = table size in GiB; 2^24 x 12 gathers like the bench MSM
+        const size_t bytes = (size_t)(arg > 0 ? arg : 1) << 30;
+        void* tab = nullptr;
+        JF_HIP(hipMalloc(&tab, bytes));
+        JF_HIP(hipMemset(tab, 0x5a, bytes));
+        const uint32_t L = 256, lanes = 786432;
+        auto launch = [&]() {
+            if (kind == 4) hipLaunchKernelGGL((k_probe_gather<1>), dim3(lanes / 128), dim3(128), 0, 0, (const uint4*)tab, (uint64_t)(bytes / 64), L, (uint32_t*)scratch);
+            else hipLaunchKernelGGL((k_probe_gather<0>), dim3(lanes / 128), dim3(128), 0, 0, (const uint4*)tab, (uint64_t)(bytes / 64), L, (uint32_t*)scratch);
+        };
+        launch();
+        JF_HIP(hipEventRecord(e0, 0));
+        launch();
+        JF_HIP(hipEventRecord(e1, 0));
+        JF_HIP(hipEventSynchronize(e1));
+        JF_HIP(hipFree(tab));
+        work = (double)lanes * L;
     } else {
         set_error("unknown probe kind %d", kind);
         return JFHIP_ERR_INVALID;
