@@ -421,8 +421,44 @@ def main():
                     "ms": round(ms, 4), "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
                                                      "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}}
             L.set_profiling(False)
+            try:   # HBM bytes per transform from the rocprofv3 --pmc passes (profiles/pmc_latest.json), if collected
+                ntt_traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json"))).get(
+                    "ntt_8x2^22_bls_hbm_bytes_per_transform")
+            except Exception:
+                ntt_traffic = None
+            for k in res_ntt:
+                res_ntt[k]["roofline"]["traffic"] = ntt_traffic
             out["ntt"] = {"workload": "8 x 2^22 BLS12-381 Fr coset NTT (h = 7), device resident",
                           "algorithmic_bytes": "64 B per element per transform", **res_ntt}
+
+        # BASELINE config 2: one commit of degree 2^20 (2^20 + 1 points, pcs/benches/kzg_gpu.rs:30-34), SRS resident;
+        # device-resident scalars (kernels only) and host scalars (scalar upload + kernels + one point back, the
+        # timed region of kzg_gpu.rs:58-83)
+        try:
+            n2 = (1 << 20) + 1
+            srs2 = L.Srs.gen_for_testing(L.BN254, beta, BN254_G, n2)
+            sc2_host = np.ascontiguousarray(scalars_host[:n2])
+            sc2 = torch.from_numpy(sc2_host.view(np.int64)).cuda()
+            o2 = torch.zeros(128, dtype=torch.uint8, device="cuda")
+            t_dev, t_host = [], []
+            for i in range(7):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                L.msm_device(srs2, sc2.data_ptr(), n2, o2.data_ptr(), stream=stream)
+                stream.sync()
+                t_dev.append((time.perf_counter() - t0) * 1e3)
+                t0 = time.perf_counter()
+                L.msm(srs2, sc2_host, stream=stream)
+                t_host.append((time.perf_counter() - t0) * 1e3)
+            md, mh = float(np.median(t_dev[2:])), float(np.median(t_host[2:]))
+            out["msm_2^20"] = {"workload": "single G1 MSM, 2^20 + 1 points, BN254 (BASELINE config 2), window_bits %d" % srs2.window_bits,
+                               "ms_device_resident": round(md, 3), "Mpts_s_device_resident": round(n2 / md / 1e3, 1),
+                               "ms_host_scalars": round(mh, 3), "Mpts_s_host_scalars": round(n2 / mh / 1e3, 1),
+                               "host_scalars": "32 MiB pageable host scalars uploaded per call + one affine point read back"}
+            srs2.free()
+            del sc2
+        except Exception as e:  # secondary measurement
+            out["msm_2^20"] = {"error": repr(e)}
 
         if not args.no_prove:
             out["plonk_prove"] = real_prove_section(L, torch, dist, 1)

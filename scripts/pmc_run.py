@@ -16,4 +16,12 @@ st = L.Stream()
 for _ in range(3):
     L.msm_device(srs, sc.data_ptr(), n, out.data_ptr(), stream=st)
 st.sync()
+# BASELINE config 3 in the same passes: 8 x 2^22 BLS12-381 Fr coset NTT, 2 forward + 2 inverse transforms
+if logn == 24:
+    m, batch = 1 << 22, 8
+    data = torch.from_numpy(bench.uniform_fr(batch * m, 0xFF7, bench.BLS_R).view(np.int64)).cuda()
+    h = L.field_op(2, "to_mont", np.array([7, 0, 0, 0], dtype=np.uint64))
+    for inverse in (False, True, False, True):
+        L.ntt_device(L.BLS12_381, data.data_ptr(), 22, batch, inverse=inverse, coset_mont=h, stream=st)
+    st.sync()
 print("done")

@@ -10,6 +10,15 @@ import json
 import sys
 
 
+def total_over(path, counter, needle_a, needle_b):
+    """sum of a counter over every launch of kernels whose name holds both needles -> bytes"""
+    t = 0.0
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter and needle_a in r["Kernel_Name"] and needle_b in r["Kernel_Name"]:
+            t += float(r["Counter_Value"])
+    return t * 1024.0
+
+
 def per_kernel(path, counter):
     d = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
@@ -31,5 +40,12 @@ if acc:
     f, w = fetch[acc[0]], write.get(acc[0], 0.0)
     out["k_msm_accumulate_hbm_bytes"] = f + w
     out["k_msm_accumulate_hbm_bytes_upper"] = 2 * f + w
+# config 3: scripts/pmc_run.py runs 4 transforms (2 forward + 2 inverse) of 8 x 2^22 BLS12-381 Fr
+nf = total_over(sys.argv[1], "FETCH_SIZE", "k_ntt_pass", "Bls381Fr")
+nw = total_over(sys.argv[2], "WRITE_SIZE", "k_ntt_pass", "Bls381Fr")
+if nf or nw:
+    out["ntt_8x2^22_bls_hbm_bytes_per_transform"] = (nf + nw) / 4.0
+    out["ntt_8x2^22_bls_hbm_bytes_per_transform_upper"] = (2 * nf + nw) / 4.0
+    out["ntt_note"] = "sum over the digit passes of one transform, averaged over 2 forward + 2 inverse; algorithmic 2.147e9"
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out)[:600])

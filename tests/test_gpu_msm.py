@@ -166,3 +166,27 @@ def test_msm_full_size_closed_form(hip):
     cs, _ = hip.msm(srs, s)
     assert (cs == C.ec_add(cv.curve_id, ca, cb)).all()
     srs.free()
+
+
+@pytest.mark.parametrize("cv", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("limbs29", ["1", "0"], ids=["limbs29", "saturated"])
+def test_msm_skewed_scalars_both_accumulators(hip, cv, limbs29, monkeypatch):
+    """Scalar distributions that put most entries into a few buckets (all equal, 0/1 witnesses, one heavy value among
+    random ones, r - 1): buckets spanning many lane slices go through k_msm_fixup_heavy.  Both bucket-accumulation
+    kernels (29-bit limbs and saturated limbs, chosen when the SRS is loaded) against the C oracle, bit for bit."""
+    monkeypatch.setenv("JFHIP_MSM_F29", limbs29)
+    n = (1 << 15) + 3
+    beta = mont_arr(cv.fr, [0xFACE + cv.curve_id])[0]
+    srs = hip.Srs.gen_for_testing(cv.curve_id, beta, pt_arr(cv, cv.g), n)
+    srs_host = srs.read(0, n)
+    rnd = rand_fr_mont(cv, n, 77)
+    same = np.repeat(rnd[:1], n, axis=0)
+    bits = mont_arr(cv.fr, [0, 1])[np.arange(n) % 3 % 2]
+    heavy = rnd.copy()
+    heavy[::2] = rnd[5]
+    minus1 = np.repeat(mont_arr(cv.fr, [cv.fr.p - 1]), n, axis=0)
+    for sc in (same, bits, heavy, minus1):
+        out, inf = hip.msm(srs, np.ascontiguousarray(sc))
+        exp = C.msm(cv.curve_id, srs_host, np.ascontiguousarray(sc))
+        assert (out == exp).all() and inf == (0 if exp.any() else 1)
+    srs.free()
