@@ -89,6 +89,15 @@ def g1_from_record(cp: CurveParams, rec: bytes):
     return (int.from_bytes(rec[:nb], "little") * rinv % cp.q, int.from_bytes(rec[nb:2 * nb], "little") * rinv % cp.q)
 
 
+def g1_to_record(cp: CurveParams, P) -> bytes:
+    """inverse of g1_from_record: canonical (x, y) or None -> packed Montgomery x||y + u32 infinity flag"""
+    nb = 8 * cp.fq_limbs64
+    if P is None:
+        return bytes(2 * nb) + (1).to_bytes(4, "little")
+    return ((P[0] * cp.fq_R % cp.q).to_bytes(nb, "little") + (P[1] * cp.fq_R % cp.q).to_bytes(nb, "little")
+            + bytes(4))
+
+
 def g1_to_mont(cp: CurveParams, P) -> np.ndarray:
     nb = 8 * cp.fq_limbs64
     buf = (P[0] * cp.fq_R % cp.q).to_bytes(nb, "little") + (P[1] * cp.fq_R % cp.q).to_bytes(nb, "little")

@@ -357,6 +357,80 @@ class Proof:
         return bytes(out)
 
 
+@dataclass
+class ProofEvaluations:
+    """plonk/src/proof_system/structs.rs:336-350"""
+    wires_evals: list
+    wire_sigma_evals: list
+    perm_next_eval: int
+
+    def as_dict(self) -> dict:
+        return dict(wires_evals=self.wires_evals, wire_sigma_evals=self.wire_sigma_evals,
+                    perm_next_eval=self.perm_next_eval)
+
+
+@dataclass
+class BatchProof:
+    """plonk/src/proof_system/structs.rs:227-249 (TurboPlonk instances: plookup_proofs_vec = [None; k])"""
+    curve: int
+    wires_poly_comms_vec: list
+    prod_perm_poly_comms_vec: list
+    poly_evals_vec: list
+    split_quot_poly_comms: list
+    opening_proof: tuple
+    shifted_opening_proof: tuple
+
+    def __len__(self) -> int:
+        return len(self.prod_perm_poly_comms_vec)
+
+    def as_dict(self) -> dict:
+        return dict(wires_poly_comms_vec=self.wires_poly_comms_vec, prod_perm_poly_comms_vec=self.prod_perm_poly_comms_vec,
+                    poly_evals_vec=[e.as_dict() for e in self.poly_evals_vec],
+                    split_quot_poly_comms=self.split_quot_poly_comms, opening_proof=self.opening_proof,
+                    shifted_opening_proof=self.shifted_opening_proof)
+
+    def to_proof(self) -> "Proof":
+        """the single-instance `Proof` (inverse of `impl From<Proof> for BatchProof`, structs.rs:275-287)"""
+        if len(self) != 1:
+            raise PlonkError("a BatchProof over %d instances is not a Proof" % len(self))
+        e = self.poly_evals_vec[0]
+        return Proof(self.curve, self.wires_poly_comms_vec[0], self.prod_perm_poly_comms_vec[0],
+                     self.split_quot_poly_comms, self.opening_proof, self.shifted_opening_proof, e.wires_evals,
+                     e.wire_sigma_evals, e.perm_next_eval)
+
+    def serialize_compressed(self) -> bytes:
+        """ark-serialize layout of `BatchProof`"""
+        cp = H.CURVES[self.curve]
+        out = bytearray()
+
+        def vec_g1(v):
+            out.extend(len(v).to_bytes(8, "little"))
+            for P in v:
+                out.extend(H.ser_g1(cp, P))
+
+        def vec_fr(v):
+            out.extend(len(v).to_bytes(8, "little"))
+            for x in v:
+                out.extend(H.ser_fr(cp, x))
+
+        k = len(self)
+        out.extend(k.to_bytes(8, "little"))
+        for comms in self.wires_poly_comms_vec:
+            vec_g1(comms)
+        vec_g1(self.prod_perm_poly_comms_vec)
+        out.extend(k.to_bytes(8, "little"))
+        for e in self.poly_evals_vec:
+            vec_fr(e.wires_evals)
+            vec_fr(e.wire_sigma_evals)
+            out.extend(H.ser_fr(cp, e.perm_next_eval))
+        out.extend(k.to_bytes(8, "little"))
+        out.extend(bytes(k))
+        vec_g1(self.split_quot_poly_comms)
+        out.extend(H.ser_g1(cp, self.opening_proof))
+        out.extend(H.ser_g1(cp, self.shifted_opening_proof))
+        return bytes(out)
+
+
 class StandardTranscript:
     """plonk/src/transcript/{mod.rs:46-186, standard.rs:14-39}"""
 
@@ -546,23 +620,53 @@ class PlonkKzgSnark:
         witness_mont: optional pre-converted witness table ((num_vars, 4) uint64 Montgomery), else converted here.
         sharded: every rank of `group` calls prove with the same inputs (same RNG state); the 13 commitments' point
         ranges are partitioned over the ranks (see _Committer); transforms and quotient run on every rank."""
-        cp = circuit.cp
+        bp = PlonkKzgSnark._batch_prove_internal(rng, [circuit], [prove_key], extra_transcript_init_msg, stream,
+                                                 None if witness_mont is None else [witness_mont], sharded, group)
+        return bp.to_proof()
+
+    @staticmethod
+    def batch_prove(rng, circuits, prove_keys, extra_transcript_init_msg: bytes | None = None, stream=None,
+                    witness_monts=None, sharded: bool = False, group=None) -> "BatchProof":
+        """k TurboPlonk instances -> ONE aggregated BatchProof (snark.rs:61-74 -> :163-430): per round the instances
+        run in order on the one RNG and the one transcript, the quotient is sum_i alpha^(3i) t_i (prover.rs:519-656)
+        and the two opening proofs fold every instance's polynomials (prover.rs:356-413)."""
+        return PlonkKzgSnark._batch_prove_internal(rng, list(circuits), list(prove_keys), extra_transcript_init_msg,
+                                                   stream, witness_monts, sharded, group)
+
+    @staticmethod
+    def _batch_prove_internal(rng, circuits, prove_keys, extra_transcript_init_msg, stream, witness_monts, sharded,
+                              group) -> "BatchProof":
+        if not circuits:
+            raise PlonkError("zero number of circuits/proving keys")
+        if len(circuits) != len(prove_keys):
+            raise PlonkError("the number of circuits %d != the number of proving keys %d"
+                             % (len(circuits), len(prove_keys)))
+        K = len(circuits)
+        cp = circuits[0].cp
         c, r = cp.curve_id, cp.r
-        pk, vk = prove_key, prove_key.vk
-        n = circuit.eval_domain_size()
-        if pk.domain_size() != n:
-            raise PlonkError("proving key domain size %d != expected domain size %d" % (pk.domain_size(), n))
-        if circuit.num_inputs() != vk.num_inputs:
-            raise PlonkError("circuit.num_inputs %d != prove_key.num_inputs %d" % (circuit.num_inputs(), vk.num_inputs))
-        log_n, W = circuit.log_n, circuit.num_wire_types
+        n = circuits[0].eval_domain_size()
+        W = circuits[0].num_wire_types
+        for circuit, pk in zip(circuits, prove_keys):
+            if circuit.eval_domain_size() != n:
+                raise PlonkError("circuit domain size %d != expected domain size %d" % (circuit.eval_domain_size(), n))
+            if pk.domain_size() != n:
+                raise PlonkError("proving key domain size %d != expected domain size %d" % (pk.domain_size(), n))
+            if circuit.num_inputs() != pk.vk.num_inputs:
+                raise PlonkError("circuit.num_inputs %d != prove_key.num_inputs %d"
+                                 % (circuit.num_inputs(), pk.vk.num_inputs))
+            if circuit.num_wire_types != W or circuit.cp is not cp:
+                raise PlonkError("inconsistent plonk circuit types")
+        log_n = circuits[0].log_n
         m = 1
         while m < n * domain_size_ratio(n, W):
             m <<= 1
         log_m = m.bit_length() - 1
         n4 = n * 4
-        ck = pk.commit_key
+        ck = prove_keys[0].commit_key        # run_3rd_round / compute_opening_proofs use prove_keys[0].commit_key
         st = _stream(stream)
-        commit = _Committer(ck, cp, st, sharded, group)
+        commits = [_Committer(pk.commit_key, cp, st, sharded, group) for pk in prove_keys] if K > 1 else \
+            [_Committer(ck, cp, st, sharded, group)]
+        commit0 = commits[0]
         mont = lambda xs: H.fr_to_mont(cp, xs)  # noqa: E731
         gen = mont([cp.fr_generator])[0]
         group_gen = pow(cp.two_adic_root, 1 << (cp.two_adicity - log_n), r)
@@ -581,8 +685,9 @@ class PlonkKzgSnark:
         tr = StandardTranscript(cp)
         if extra_transcript_init_msg is not None:
             tr.append_message(b"extra info", extra_transcript_init_msg)
-        pub_input = circuit.public_input()
-        tr.append_vk_and_pub_input(vk, pub_input)
+        pub_inputs = [circuit.public_input() for circuit in circuits]
+        for pk, pub_input in zip(prove_keys, pub_inputs):
+            tr.append_vk_and_pub_input(pk.vk, pub_input)
         tick("transcript_init")
 
         def mask(poly: torch.Tensor, hiding_bound: int):
@@ -593,49 +698,77 @@ class PlonkKzgSnark:
             poly[:k] = _dev_fr(mont([(x - y) % r for x, y in zip(low, b)]))
             poly[n4:n4 + k] = _dev_fr(mont(b))
 
-        # ---- Round 1 (prover.rs:77-91): wire polynomials, public-input polynomial
-        wit = _dev_fr(witness_mont if witness_mont is not None else mont(circuit.witness)).view(-1, 4)
-        wire_vals = wit[pk.wire_variables].view(W, n4)
-        buf = torch.empty(W + 1, n4, dtype=torch.int64, device="cuda")
-        buf[:W].copy_(wire_vals)
-        buf[W].zero_()
-        if pub_input:
-            buf[W, :4 * len(pub_input)] = _dev_fr(mont(pub_input))   # io gates sit in rows 0 .. num_inputs-1
-        L.ntt_device(c, buf.data_ptr(), log_n, W + 1, inverse=True, stream=st)
-        tick("r1_gather_intt")
+        def lincomb(terms, out_len: int) -> torch.Tensor:
+            """sum_k s_k * poly_k for (scalar, device poly, length) terms; jfhip_poly_lincomb_device takes <= 32
+            polynomials per call, longer sums chain through the running total"""
+            out = torch.zeros(out_len * 4, dtype=torch.int64, device="cuda")
+            acc = None
+            for at in range(0, len(terms), 31):
+                chunk = list(terms[at:at + 31])
+                if acc is not None:
+                    chunk.append((1, acc, out_len))
+                    out = torch.zeros(out_len * 4, dtype=torch.int64, device="cuda")
+                L.poly_lincomb_device(c, [p.data_ptr() for _, p, _ in chunk], [k for _, _, k in chunk],
+                                      mont([s % r for s, _, _ in chunk]), out.data_ptr(), out_len, stream=st)
+                acc = out
+            return out
+
+        # ---- Round 1 (prover.rs:77-91): wire polynomials, public-input polynomial; instances in order
         ln = n + 3
-        wire_polys = torch.zeros(W, ln * 4, dtype=torch.int64, device="cuda")
-        wire_polys[:, :n4].copy_(buf[:W])
-        pub_poly = buf[W]
-        # mask_polynomial for the W wire polynomials with ONE read-back and two uploads (RNG draws in the reference's
-        # order: b_0, b_1 of wire 0, then wire 1, ...)
-        bs = [[H.fr_rand(cp, rng) for _ in range(2)] for _ in range(W)]
-        low = _read_fr(cp, wire_polys[:, :8].contiguous().view(-1))
-        wire_polys[:, :8] = _dev_fr(mont([(low[2 * j + i] - bs[j][i]) % r for j in range(W) for i in range(2)])).view(W, 8)
-        wire_polys[:, n4:n4 + 8] = _dev_fr(mont([b for row in bs for b in row])).view(W, 8)
-        tick("r1_mask")
-        wires_poly_comms = commit([wire_polys[j] for j in range(W)], [n + 2] * W)
-        tr.append_commitments(b"witness_poly_comms", wires_poly_comms)
-        tick("r1_commit")
+        l4 = ln * 4
+        wire_vals_v, wire_polys_v, pub_poly_v, wires_poly_comms_vec = [], [], [], []
+        for i, (circuit, pk) in enumerate(zip(circuits, prove_keys)):
+            wm = witness_monts[i] if witness_monts is not None and witness_monts[i] is not None else mont(circuit.witness)
+            wit = _dev_fr(wm).view(-1, 4)
+            wire_vals = wit[pk.wire_variables].view(W, n4)
+            buf = torch.empty(W + 1, n4, dtype=torch.int64, device="cuda")
+            buf[:W].copy_(wire_vals)
+            buf[W].zero_()
+            if pub_inputs[i]:
+                buf[W, :4 * len(pub_inputs[i])] = _dev_fr(mont(pub_inputs[i]))   # io gates sit in rows 0 .. num_inputs-1
+            L.ntt_device(c, buf.data_ptr(), log_n, W + 1, inverse=True, stream=st)
+            tick("r1_gather_intt")
+            wire_polys = torch.zeros(W, l4, dtype=torch.int64, device="cuda")
+            wire_polys[:, :n4].copy_(buf[:W])
+            # mask_polynomial for the W wire polynomials with ONE read-back and two uploads (RNG draws in the
+            # reference's order: b_0, b_1 of wire 0, then wire 1, ...)
+            bs = [[H.fr_rand(cp, rng) for _ in range(2)] for _ in range(W)]
+            low = _read_fr(cp, wire_polys[:, :8].contiguous().view(-1))
+            wire_polys[:, :8] = _dev_fr(mont([(low[2 * j + t] - bs[j][t]) % r for j in range(W) for t in range(2)])).view(W, 8)
+            wire_polys[:, n4:n4 + 8] = _dev_fr(mont([b for row in bs for b in row])).view(W, 8)
+            tick("r1_mask")
+            comms = commits[i]([wire_polys[j] for j in range(W)], [n + 2] * W)
+            tr.append_commitments(b"witness_poly_comms", comms)
+            tick("r1_commit")
+            wire_vals_v.append(wire_vals)
+            wire_polys_v.append(wire_polys)
+            pub_poly_v.append(buf[W])
+            wires_poly_comms_vec.append(comms)
 
         # ---- Round 2 (prover.rs:128-142; grand product constraint_system.rs:1394-1420)
         beta = tr.get_challenge(b"beta")
         gamma = tr.get_challenge(b"gamma")
         bg = mont([beta, gamma])
-        perm_poly = torch.zeros(ln * 4, dtype=torch.int64, device="cuda")
-        L.plonk_perm_product_device(c, log_n, W, wire_vals.data_ptr(), pk.id_perm_vals.data_ptr(),
-                                    pk.sigma_vals.data_ptr(), bg[0], bg[1], perm_poly.data_ptr(), stream=st)
-        L.ntt_device(c, perm_poly.data_ptr(), log_n, 1, inverse=True, stream=st)
-        mask(perm_poly, 2)
-        tick("r2_product_intt_mask")
-        prod_perm_poly_comm = commit([perm_poly], [n + 3])[0]
-        tr.append_commitments(b"perm_poly_comms", [prod_perm_poly_comm])
-        tick("r2_commit")
+        perm_poly_v, prod_perm_poly_comms_vec = [], []
+        for i, pk in enumerate(prove_keys):
+            perm_poly = torch.zeros(l4, dtype=torch.int64, device="cuda")
+            L.plonk_perm_product_device(c, log_n, W, wire_vals_v[i].data_ptr(), pk.id_perm_vals.data_ptr(),
+                                        pk.sigma_vals.data_ptr(), bg[0], bg[1], perm_poly.data_ptr(), stream=st)
+            L.ntt_device(c, perm_poly.data_ptr(), log_n, 1, inverse=True, stream=st)
+            mask(perm_poly, 2)
+            tick("r2_product_intt_mask")
+            comm = commits[i]([perm_poly], [n + 3])[0]
+            tr.append_commitments(b"perm_poly_comms", [comm])
+            tick("r2_commit")
+            perm_poly_v.append(perm_poly)
+            prod_perm_poly_comms_vec.append(comm)
+        del wire_vals_v
 
         # ---- Round 3 (prover.rs:183-198, 491-661, 894-943)
         alpha = tr.get_challenge(b"alpha")
+        alpha_3 = pow(alpha, 3, r)
+        alpha_bases = [pow(alpha_3, i, r) for i in range(K)]
         NSEL = N_TURBO_PLONK_SELECTORS
-        l4 = ln * 4
         # coset sharding (SURVEY.md 8e): rank g of G evaluates the slice i = g (mod G) of the quotient coset, a coset of
         # size ml = m / G with offset h w_m^g; one all_gather of the slices' iNTTs rebuilds the quotient polynomial
         G, g = 1, 0
@@ -650,50 +783,55 @@ class PlonkKzgSnark:
         log_ml = ml.bit_length() - 1
         off_int = slice_offset(cp, m, g)
         off = mont([off_int])[0]
-        if pk.coset_evals is not None:
-            # selector / sigma coset evaluations are resident with the proving key: 7 transforms instead of 25
-            fixed = pk.coset_evals
-            if fixed.shape != (NSEL + W, ml * 4) or pk.coset_slice != (g, G):
-                raise PlonkError("proving key coset evaluations were kept for another slice of the quotient coset")
-            npolys, o_w = W + 2, 0
-            sel_ptr, sig_ptr = fixed[0].data_ptr(), fixed[NSEL].data_ptr()
-        else:
-            npolys, o_w = NSEL + 2 * W + 2, NSEL + W
-        o_z, o_pi = o_w + W, o_w + W + 1
-        cs = torch.empty(npolys, ml * 4, dtype=torch.int64, device="cuda")
         lc4 = min(l4, ml * 4)
-        cs[:, n4:lc4].zero_()
-        if pk.coset_evals is None:
-            cs[:NSEL, :n4].copy_(pk.selectors)
-            cs[NSEL:o_w, :n4].copy_(pk.sigmas)
-            sel_ptr, sig_ptr = cs[0].data_ptr(), cs[NSEL].data_ptr()
-        cs[o_w:o_z, :lc4].copy_(wire_polys[:, :lc4])
-        cs[o_z, :lc4].copy_(perm_poly[:lc4])
-        cs[o_pi, :n4].copy_(pub_poly)
-        if lc4 < l4:
-            # ml = n < n + 3 coefficients: reduce mod X^ml - off^ml (the slice's vanishing polynomial)
-            fold = mont([1, pow(off_int, ml, r)])
-            k = (l4 - lc4) // 4
-            tmp = torch.empty(W + 1, k * 4, dtype=torch.int64, device="cuda")
-            for j, poly in enumerate([wire_polys[j] for j in range(W)] + [perm_poly]):
-                L.poly_lincomb_device(c, [poly.data_ptr(), poly.data_ptr() + lc4 * 8], [k, k], fold, tmp[j].data_ptr(), k,
-                                      stream=st)
-            cs[o_w:o_z + 1, :k * 4].copy_(tmp)
-        L.ntt_device(c, cs.data_ptr(), log_ml, npolys, inverse=False, coset_mont=off, in_len=lc4 // 4, stream=st)
-        tick("r3_coset_ntts")
         quot = torch.zeros(m * 4, dtype=torch.int64, device="cuda")
+        part = torch.zeros(ml * 4, dtype=torch.int64, device="cuda") if G > 1 else None
+        for i, pk in enumerate(prove_keys):
+            vk, wire_polys, perm_poly = pk.vk, wire_polys_v[i], perm_poly_v[i]
+            if pk.coset_evals is not None:
+                # selector / sigma coset evaluations are resident with the proving key: 7 transforms instead of 25
+                fixed = pk.coset_evals
+                if fixed.shape != (NSEL + W, ml * 4) or pk.coset_slice != (g, G):
+                    raise PlonkError("proving key coset evaluations were kept for another slice of the quotient coset")
+                npolys, o_w = W + 2, 0
+                sel_ptr, sig_ptr = fixed[0].data_ptr(), fixed[NSEL].data_ptr()
+            else:
+                npolys, o_w = NSEL + 2 * W + 2, NSEL + W
+            o_z, o_pi = o_w + W, o_w + W + 1
+            cs = torch.empty(npolys, ml * 4, dtype=torch.int64, device="cuda")
+            cs[:, n4:lc4].zero_()
+            if pk.coset_evals is None:
+                cs[:NSEL, :n4].copy_(pk.selectors)
+                cs[NSEL:o_w, :n4].copy_(pk.sigmas)
+                sel_ptr, sig_ptr = cs[0].data_ptr(), cs[NSEL].data_ptr()
+            cs[o_w:o_z, :lc4].copy_(wire_polys[:, :lc4])
+            cs[o_z, :lc4].copy_(perm_poly[:lc4])
+            cs[o_pi, :n4].copy_(pub_poly_v[i])
+            if lc4 < l4:
+                # ml = n < n + 3 coefficients: reduce mod X^ml - off^ml (the slice's vanishing polynomial)
+                fold = mont([1, pow(off_int, ml, r)])
+                k = (l4 - lc4) // 4
+                tmp = torch.empty(W + 1, k * 4, dtype=torch.int64, device="cuda")
+                for j, poly in enumerate([wire_polys[j] for j in range(W)] + [perm_poly]):
+                    L.poly_lincomb_device(c, [poly.data_ptr(), poly.data_ptr() + lc4 * 8], [k, k], fold,
+                                          tmp[j].data_ptr(), k, stream=st)
+                cs[o_w:o_z + 1, :k * 4].copy_(tmp)
+            L.ntt_device(c, cs.data_ptr(), log_ml, npolys, inverse=False, coset_mont=off, in_len=lc4 // 4, stream=st)
+            tick("r3_coset_ntts")
+            chal = mont([alpha, beta, gamma, alpha_bases[i]])
+            if G == 1:
+                L.plonk_quotient_turbo_device(c, log_n, log_m, sel_ptr, sig_ptr, cs[o_w].data_ptr(),
+                                              cs[o_z].data_ptr(), cs[o_pi].data_ptr(), mont(vk.k), chal,
+                                              quot.data_ptr(), stream=st)
+            else:
+                L.plonk_quotient_coset_device(c, W, log_n, log_ml, off, sel_ptr, sig_ptr, cs[o_w].data_ptr(),
+                                              cs[o_z].data_ptr(), cs[o_pi].data_ptr(), 0, mont(vk.k), chal,
+                                              part.data_ptr(), stream=st)
+            del cs                             # stream-ordered: the next allocation is used on the same stream
+            tick("r3_quotient_intt")
         if G == 1:
-            L.plonk_quotient_turbo_device(c, log_n, log_m, sel_ptr, sig_ptr, cs[o_w].data_ptr(),
-                                          cs[o_z].data_ptr(), cs[o_pi].data_ptr(), mont(vk.k),
-                                          mont([alpha, beta, gamma, 1]), quot.data_ptr(), stream=st)
-            del cs
             L.ntt_device(c, quot.data_ptr(), log_m, 1, inverse=True, coset_mont=gen, stream=st)
         else:
-            part = torch.zeros(ml * 4, dtype=torch.int64, device="cuda")
-            L.plonk_quotient_coset_device(c, W, log_n, log_ml, off, sel_ptr, sig_ptr, cs[o_w].data_ptr(),
-                                          cs[o_z].data_ptr(), cs[o_pi].data_ptr(), 0, mont(vk.k),
-                                          mont([alpha, beta, gamma, 1]), part.data_ptr(), stream=st)
-            del cs
             L.ntt_device(c, part.data_ptr(), log_ml, 1, inverse=True, coset_mont=off, stream=st)
             st.sync()
             if tdist.get_backend(group) == "gloo":
@@ -730,70 +868,330 @@ class PlonkKzgSnark:
         split[:, :4] = _dev_fr(mont(firsts)).view(W, 4)
         split_lens = [n + 3] * (W - 1) + [last_len]
         tick("r3_split_mask")
-        split_quot_poly_comms = commit([split[j] for j in range(W)], split_lens)
+        split_quot_poly_comms = commit0([split[j] for j in range(W)], split_lens)
         tr.append_commitments(b"quot_poly_comms", split_quot_poly_comms)
         tick("r3_commit")
 
-        # ---- Round 4 (prover.rs:205-229): evaluations
+        # ---- Round 4 (prover.rs:205-229): evaluations, instances in order
         zeta = tr.get_challenge(b"zeta")
         zeta_omega = zeta * group_gen % r
-        evals_dev = torch.zeros((2 * W) * 4, dtype=torch.int64, device="cuda")
-        at_zeta = [(wire_polys[j], n + 2) for j in range(W)] + [(pk.sigmas[j], n) for j in range(W - 1)]
-        L.poly_eval_batch_device(c, [p.data_ptr() for p, _ in at_zeta], [k for _, k in at_zeta], mont([zeta])[0],
-                                 evals_dev.data_ptr(), stream=st)
-        L.poly_eval_batch_device(c, [perm_poly.data_ptr()], [n + 3], mont([zeta_omega])[0],
-                                 evals_dev.data_ptr() + (2 * W - 1) * 32, stream=st)
-        ev = _read_fr(cp, evals_dev)
-        wires_evals, wire_sigma_evals, perm_next_eval = ev[:W], ev[W:2 * W - 1], ev[2 * W - 1]
-        tr.append_field_elems(b"wire_evals", wires_evals)
-        tr.append_field_elems(b"wire_sigma_evals", wire_sigma_evals)
-        tr.append_field_elems(b"perm_next_eval", [perm_next_eval])
+        zm, zom = mont([zeta])[0], mont([zeta_omega])[0]
+        evals_dev = torch.zeros(K * (2 * W) * 4, dtype=torch.int64, device="cuda")
+        at_zeta_v = []
+        for i, pk in enumerate(prove_keys):
+            at_zeta = [(wire_polys_v[i][j], n + 2) for j in range(W)] + [(pk.sigmas[j], n) for j in range(W - 1)]
+            base = evals_dev.data_ptr() + i * 2 * W * 32
+            L.poly_eval_batch_device(c, [p.data_ptr() for p, _ in at_zeta], [k for _, k in at_zeta], zm, base, stream=st)
+            L.poly_eval_batch_device(c, [perm_poly_v[i].data_ptr()], [n + 3], zom, base + (2 * W - 1) * 32, stream=st)
+            at_zeta_v.append(at_zeta)
+        ev_all = _read_fr(cp, evals_dev)
+        poly_evals_vec = []
+        for i in range(K):
+            ev = ev_all[i * 2 * W:(i + 1) * 2 * W]
+            pe = ProofEvaluations(ev[:W], ev[W:2 * W - 1], ev[2 * W - 1])
+            tr.append_field_elems(b"wire_evals", pe.wires_evals)
+            tr.append_field_elems(b"wire_sigma_evals", pe.wire_sigma_evals)
+            tr.append_field_elems(b"perm_next_eval", [pe.perm_next_eval])
+            poly_evals_vec.append(pe)
         tick("r4_evals")
 
-        # linearisation polynomial (snark.rs:364-389; prover.rs:299-352, 946-1015), one lincomb on the device
+        # linearisation polynomial (snark.rs:364-389; prover.rs:299-352, 946-1015) as device linear combinations
         vanish_eval = (pow(zeta, n, r) - 1) % r
         zeta_to_n_plus_2 = (vanish_eval + 1) * zeta % r * zeta % r
+        lagrange_1_eval = vanish_eval * pow(n * (zeta - 1) % r, -1, r) % r
         terms = []
         coeff = 1
         for i in range(W):
             if i:
                 coeff = coeff * zeta_to_n_plus_2 % r
             terms.append((-vanish_eval * coeff % r, split[i], split_lens[i]))
-        w = wires_evals
+        for i, pk in enumerate(prove_keys):
+            ab, vk, pe = alpha_bases[i], pk.vk, poly_evals_vec[i]
+            w = pe.wires_evals
+            q_scalars = [w[0], w[1], w[2], w[3], w[0] * w[1], w[2] * w[3], pow(w[0], 5, r), pow(w[1], 5, r),
+                         pow(w[2], 5, r), pow(w[3], 5, r), -w[4], 1, w[0] * w[1] * w[2] * w[3] * w[4]]
+            terms += [(s % r * ab % r, pk.selectors[j], n) for j, s in enumerate(q_scalars)]
+            cz = alpha
+            for j in range(W):
+                cz = cz * (w[j] + beta * vk.k[j] % r * zeta + gamma) % r
+            cz = (cz + alpha * alpha % r * lagrange_1_eval) % r
+            terms.append((cz * ab % r, perm_poly_v[i], n + 3))
+            csig = alpha * beta % r * pe.perm_next_eval % r
+            for j in range(W - 1):
+                csig = csig * (w[j] + beta * pe.wire_sigma_evals[j] + gamma) % r
+            terms.append((-csig * ab % r, pk.sigmas[W - 1], n))
+        lin_poly = lincomb(terms, n + 3)
+        tick("r4_lin_poly")
+
+        # ---- Round 5 (prover.rs:356-413, 470-488): batched opening quotients over every instance
+        v = tr.get_challenge(b"v")
+        polys = [(lin_poly, n + 3)]
+        for at_zeta in at_zeta_v:
+            polys += at_zeta
+        open_terms, cur = [], 1
+        for p, k in polys:
+            open_terms.append((cur, p, k))
+            cur = cur * v % r
+        open_poly = lincomb(open_terms, n + 3)
+        if K == 1:
+            shifted_poly = perm_poly_v[0]
+        else:
+            sh_terms, cur = [], 1
+            for z in perm_poly_v:
+                sh_terms.append((cur, z, n + 3))
+                cur = cur * v % r
+            shifted_poly = lincomb(sh_terms, n + 3)
+        wpoly = torch.zeros(2, l4, dtype=torch.int64, device="cuda")
+        L.poly_divide_linear_device(c, open_poly.data_ptr(), n + 3, zm, wpoly[0].data_ptr(), stream=st)
+        L.poly_divide_linear_device(c, shifted_poly.data_ptr(), n + 3, zom, wpoly[1].data_ptr(), stream=st)
+        tick("r5_open_polys")
+        opening_proof, shifted_opening_proof = commit0([wpoly[0][4:], wpoly[1][4:]], [n + 2, n + 2])
+        tick("r5_commit")
+
+        return BatchProof(c, wires_poly_comms_vec, prod_perm_poly_comms_vec, poly_evals_vec, split_quot_poly_comms,
+                          opening_proof, shifted_opening_proof)
+
+    @staticmethod
+    def batch_prove_one_per_rank(rng, circuit: PlonkCircuit, prove_key: ProvingKey,
+                                 extra_transcript_init_msg: bytes | None = None, stream=None,
+                                 witness_mont: np.ndarray | None = None, group=None) -> "BatchProof":
+        """batch_prove with ONE circuit per GPU (BASELINE config 5's layout): rank i of `group` holds
+        instance i (its circuit and proving key) and every rank returns the SAME BatchProof, byte-identical to
+        batch_prove(rng, [circuit_0 .. circuit_{G-1}], ...) on one GPU from the same RNG state.
+        * every rank runs the same transcript and the same RNG (it draws every instance's blinding in the reference's
+          order, snark.rs:245-318, prover.rs:926-940, and uses its own);
+        * per-instance commitments and evaluations are exchanged with one small all_gather per round;
+        * everything that mixes instances -- the quotient sum_i alpha^(3i) t_i, its split, the linearisation and the
+          two opening polynomials (prover.rs:644-655, 356-413) -- is linear in the instances: each rank keeps its own
+          contribution, commits it without normalising (jfhip_msm_partial_device) and the aggregated commitment is
+          the group sum of the gathered partial sums.  No polynomial crosses xGMI."""
+        import torch.distributed as tdist
+
+        from . import dist as jdist
+
+        G = tdist.get_world_size(group)
+        me = tdist.get_rank(group)
+        cp = circuit.cp
+        c, r = cp.curve_id, cp.r
+        pk, vk = prove_key, prove_key.vk
+        n, log_n, W = circuit.eval_domain_size(), circuit.log_n, circuit.num_wire_types
+        if pk.domain_size() != n:
+            raise PlonkError("proving key domain size %d != expected domain size %d" % (pk.domain_size(), n))
+        if circuit.num_inputs() != vk.num_inputs:
+            raise PlonkError("circuit.num_inputs %d != prove_key.num_inputs %d" % (circuit.num_inputs(), vk.num_inputs))
+        m = 1
+        while m < n * domain_size_ratio(n, W):
+            m <<= 1
+        log_m = m.bit_length() - 1
+        n4, ln = n * 4, n + 3
+        l4 = ln * 4
+        st = _stream(stream)
+        commit = _Committer(pk.commit_key, cp, st)
+        engine = jdist.HipMsmEngine(L, pk.commit_key, st)
+        mont = lambda xs: H.fr_to_mont(cp, xs)  # noqa: E731
+        gen = mont([cp.fr_generator])[0]
+        group_gen = pow(cp.two_adic_root, 1 << (cp.two_adicity - log_n), r)
+        rec = 16 * cp.fq_limbs64 + 4
+
+        def gather_points(points) -> list:
+            """[rank][j] of every rank's affine points (packed records through one all_gather)"""
+            raw = bytearray()
+            for P in points:
+                raw += H.g1_to_record(cp, P)
+            mine = torch.frombuffer(raw, dtype=torch.uint8).cuda()
+            out = jdist._all_gather_bytes(mine, G, group).cpu().numpy().tobytes()
+            k = len(points)
+            return [[H.g1_from_record(cp, out[(q * k + j) * rec:(q * k + j + 1) * rec]) for j in range(k)]
+                    for q in range(G)]
+
+        def gather_ints(xs) -> list:
+            raw = b"".join(int(x).to_bytes(32, "little") for x in xs)
+            mine = torch.frombuffer(bytearray(raw), dtype=torch.uint8).cuda()
+            out = jdist._all_gather_bytes(mine, G, group).cpu().numpy().tobytes()
+            k = len(xs)
+            return [[int.from_bytes(out[(q * k + j) * 32:(q * k + j + 1) * 32], "little") for j in range(k)]
+                    for q in range(G)]
+
+        def aggregated_commit(polys, lens) -> list:
+            """sum over ranks of commit(rank's polynomial): un-normalised partial sums, one all_gather, local fold"""
+            for k in lens:
+                if k - 1 > len(pk.commit_key) - 1:
+                    raise PlonkError("poly degree %d is larger than allowed %d" % (k - 1, len(pk.commit_key) - 1))
+            parts = torch.cat([engine.partial(p[:4 * k]) for p, k in zip(polys, lens)])
+            st.sync()
+            allp = jdist._all_gather_bytes(parts, G, group).view(G, len(polys), engine.partial_bytes)
+            per = allp.transpose(0, 1).contiguous()
+            out = []
+            for j in range(len(polys)):
+                raw = engine.fold(per[j].reshape(-1), G).cpu().numpy().tobytes()
+                out.append(H.g1_from_record(cp, raw))
+            return out
+
+        def lincomb(terms, out_len: int) -> torch.Tensor:
+            out = torch.zeros(out_len * 4, dtype=torch.int64, device="cuda")
+            L.poly_lincomb_device(c, [p.data_ptr() for _, p, _ in terms], [k for _, _, k in terms],
+                                  mont([s % r for s, _, _ in terms]), out.data_ptr(), out_len, stream=st)
+            return out
+
+        # every rank needs every instance's verifying key and public input for the shared transcript
+        pub_input = circuit.public_input()
+        everyone = [None] * G
+        tdist.all_gather_object(everyone, (vk, pub_input), group=group)
+        for other_vk, _ in everyone:
+            if other_vk.domain_size != n:
+                raise PlonkError("circuit domain size %d != expected domain size %d" % (other_vk.domain_size, n))
+        tr = StandardTranscript(cp)
+        if extra_transcript_init_msg is not None:
+            tr.append_message(b"extra info", extra_transcript_init_msg)
+        for other_vk, other_pub in everyone:
+            tr.append_vk_and_pub_input(other_vk, other_pub)
+
+        # ---- Round 1: the RNG draws of all instances in order, this rank keeps its own
+        bs = [[[H.fr_rand(cp, rng) for _ in range(2)] for _ in range(W)] for _ in range(G)][me]
+        wit = _dev_fr(witness_mont if witness_mont is not None else mont(circuit.witness)).view(-1, 4)
+        wire_vals = wit[pk.wire_variables].view(W, n4)
+        buf = torch.empty(W + 1, n4, dtype=torch.int64, device="cuda")
+        buf[:W].copy_(wire_vals)
+        buf[W].zero_()
+        if pub_input:
+            buf[W, :4 * len(pub_input)] = _dev_fr(mont(pub_input))
+        L.ntt_device(c, buf.data_ptr(), log_n, W + 1, inverse=True, stream=st)
+        wire_polys = torch.zeros(W, l4, dtype=torch.int64, device="cuda")
+        wire_polys[:, :n4].copy_(buf[:W])
+        pub_poly = buf[W]
+        low = _read_fr(cp, wire_polys[:, :8].contiguous().view(-1))
+        wire_polys[:, :8] = _dev_fr(mont([(low[2 * j + t] - bs[j][t]) % r for j in range(W) for t in range(2)])).view(W, 8)
+        wire_polys[:, n4:n4 + 8] = _dev_fr(mont([b for row in bs for b in row])).view(W, 8)
+        wires_poly_comms_vec = gather_points(commit([wire_polys[j] for j in range(W)], [n + 2] * W))
+        for comms in wires_poly_comms_vec:
+            tr.append_commitments(b"witness_poly_comms", comms)
+
+        # ---- Round 2
+        beta = tr.get_challenge(b"beta")
+        gamma = tr.get_challenge(b"gamma")
+        bg = mont([beta, gamma])
+        b = [[H.fr_rand(cp, rng) for _ in range(3)] for _ in range(G)][me]
+        perm_poly = torch.zeros(l4, dtype=torch.int64, device="cuda")
+        L.plonk_perm_product_device(c, log_n, W, wire_vals.data_ptr(), pk.id_perm_vals.data_ptr(),
+                                    pk.sigma_vals.data_ptr(), bg[0], bg[1], perm_poly.data_ptr(), stream=st)
+        L.ntt_device(c, perm_poly.data_ptr(), log_n, 1, inverse=True, stream=st)
+        low = _read_fr(cp, perm_poly[:12])
+        perm_poly[:12] = _dev_fr(mont([(x - y) % r for x, y in zip(low, b)]))
+        perm_poly[n4:n4 + 12] = _dev_fr(mont(b))
+        prod_perm_poly_comms_vec = [row[0] for row in gather_points(commit([perm_poly], [n + 3]))]
+        tr.append_commitments(b"perm_poly_comms", prod_perm_poly_comms_vec)
+
+        # ---- Round 3: this rank's share alpha^(3 me) t_me of the quotient
+        alpha = tr.get_challenge(b"alpha")
+        alpha_base = pow(alpha, 3 * me, r)
+        NSEL = N_TURBO_PLONK_SELECTORS
+        if pk.coset_evals is not None:
+            fixed = pk.coset_evals
+            if fixed.shape != (NSEL + W, m * 4) or pk.coset_slice != (0, 1):
+                raise PlonkError("proving key coset evaluations were kept for another slice of the quotient coset")
+            npolys, o_w = W + 2, 0
+            sel_ptr, sig_ptr = fixed[0].data_ptr(), fixed[NSEL].data_ptr()
+        else:
+            npolys, o_w = NSEL + 2 * W + 2, NSEL + W
+        o_z, o_pi = o_w + W, o_w + W + 1
+        cs = torch.empty(npolys, m * 4, dtype=torch.int64, device="cuda")
+        cs[:, n4:l4].zero_()
+        if pk.coset_evals is None:
+            cs[:NSEL, :n4].copy_(pk.selectors)
+            cs[NSEL:o_w, :n4].copy_(pk.sigmas)
+            sel_ptr, sig_ptr = cs[0].data_ptr(), cs[NSEL].data_ptr()
+        cs[o_w:o_z, :l4].copy_(wire_polys)
+        cs[o_z, :l4].copy_(perm_poly)
+        cs[o_pi, :n4].copy_(pub_poly)
+        L.ntt_device(c, cs.data_ptr(), log_m, npolys, inverse=False, coset_mont=gen, in_len=ln, stream=st)
+        quot = torch.zeros(m * 4, dtype=torch.int64, device="cuda")
+        L.plonk_quotient_turbo_device(c, log_n, log_m, sel_ptr, sig_ptr, cs[o_w].data_ptr(), cs[o_z].data_ptr(),
+                                      cs[o_pi].data_ptr(), mont(vk.k), mont([alpha, beta, gamma, alpha_base]),
+                                      quot.data_ptr(), stream=st)
+        del cs
+        L.ntt_device(c, quot.data_ptr(), log_m, 1, inverse=True, coset_mont=gen, stream=st)
+        expected_degree = W * (n + 1) + 2
+        tail_nonzero = int(bool(torch.any(quot[(expected_degree + 1) * 4:] != 0).item()))
+        top = _read_fr(cp, quot[expected_degree * 4:(expected_degree + 1) * 4])[0]
+        checks = gather_ints([tail_nonzero, top])
+        if any(t for t, _ in checks) or sum(x for _, x in checks) % r == 0:
+            raise PlonkError("WrongQuotientPolyDegree(expected %d)" % expected_degree)
+        split = torch.zeros(W, l4, dtype=torch.int64, device="cuda")
+        step = (n + 2) * 4
+        for i in range(W - 1):
+            split[i, :step].copy_(quot[i * step:(i + 1) * step])
+        last_len = expected_degree + 1 - (W - 1) * (n + 2)
+        split[W - 1, :last_len * 4].copy_(quot[(W - 1) * step:(expected_degree + 1) * 4])
+        del quot
+        randomizers = [H.fr_rand(cp, rng) for _ in range(W - 1)]     # drawn on every rank, applied to instance 0's share
+        if me == 0:
+            firsts = _read_fr(cp, split[:, :4].contiguous())
+            last_randomizer = 0
+            for i in range(W - 1):
+                firsts[i] = (firsts[i] - last_randomizer) % r
+                split[i, step:step + 4] = _dev_fr(mont([randomizers[i]]))
+                last_randomizer = randomizers[i]
+            firsts[W - 1] = (firsts[W - 1] - last_randomizer) % r
+            split[:, :4] = _dev_fr(mont(firsts)).view(W, 4)
+        split_lens = [n + 3] * (W - 1) + [last_len]
+        split_quot_poly_comms = aggregated_commit([split[j] for j in range(W)], split_lens)
+        tr.append_commitments(b"quot_poly_comms", split_quot_poly_comms)
+
+        # ---- Round 4
+        zeta = tr.get_challenge(b"zeta")
+        zeta_omega = zeta * group_gen % r
+        zm, zom = mont([zeta])[0], mont([zeta_omega])[0]
+        evals_dev = torch.zeros((2 * W) * 4, dtype=torch.int64, device="cuda")
+        at_zeta = [(wire_polys[j], n + 2) for j in range(W)] + [(pk.sigmas[j], n) for j in range(W - 1)]
+        L.poly_eval_batch_device(c, [p.data_ptr() for p, _ in at_zeta], [k for _, k in at_zeta], zm,
+                                 evals_dev.data_ptr(), stream=st)
+        L.poly_eval_batch_device(c, [perm_poly.data_ptr()], [n + 3], zom, evals_dev.data_ptr() + (2 * W - 1) * 32,
+                                 stream=st)
+        poly_evals_vec = []
+        for ev in gather_ints(_read_fr(cp, evals_dev)):
+            pe = ProofEvaluations(ev[:W], ev[W:2 * W - 1], ev[2 * W - 1])
+            tr.append_field_elems(b"wire_evals", pe.wires_evals)
+            tr.append_field_elems(b"wire_sigma_evals", pe.wire_sigma_evals)
+            tr.append_field_elems(b"perm_next_eval", [pe.perm_next_eval])
+            poly_evals_vec.append(pe)
+        # this rank's share of the linearisation polynomial: quotient part over its split share + its instance's part
+        vanish_eval = (pow(zeta, n, r) - 1) % r
+        zeta_to_n_plus_2 = (vanish_eval + 1) * zeta % r * zeta % r
+        lagrange_1_eval = vanish_eval * pow(n * (zeta - 1) % r, -1, r) % r
+        terms = []
+        coeff = 1
+        for i in range(W):
+            if i:
+                coeff = coeff * zeta_to_n_plus_2 % r
+            terms.append((-vanish_eval * coeff % r, split[i], split_lens[i]))
+        pe = poly_evals_vec[me]
+        w = pe.wires_evals
         q_scalars = [w[0], w[1], w[2], w[3], w[0] * w[1], w[2] * w[3], pow(w[0], 5, r), pow(w[1], 5, r), pow(w[2], 5, r),
                      pow(w[3], 5, r), -w[4], 1, w[0] * w[1] * w[2] * w[3] * w[4]]
-        terms += [(s % r, pk.selectors[j], n) for j, s in enumerate(q_scalars)]
-        lagrange_1_eval = vanish_eval * pow(n * (zeta - 1) % r, -1, r) % r
+        terms += [(s % r * alpha_base % r, pk.selectors[j], n) for j, s in enumerate(q_scalars)]
         cz = alpha
         for j in range(W):
             cz = cz * (w[j] + beta * vk.k[j] % r * zeta + gamma) % r
         cz = (cz + alpha * alpha % r * lagrange_1_eval) % r
-        terms.append((cz, perm_poly, n + 3))
-        csig = alpha * beta % r * perm_next_eval % r
+        terms.append((cz * alpha_base % r, perm_poly, n + 3))
+        csig = alpha * beta % r * pe.perm_next_eval % r
         for j in range(W - 1):
-            csig = csig * (w[j] + beta * wire_sigma_evals[j] + gamma) % r
-        terms.append((-csig % r, pk.sigmas[W - 1], n))
-        lin_poly = torch.zeros(l4, dtype=torch.int64, device="cuda")
-        L.poly_lincomb_device(c, [p.data_ptr() for _, p, _ in terms], [k for _, _, k in terms],
-                              mont([s for s, _, _ in terms]), lin_poly.data_ptr(), n + 3, stream=st)
+            csig = csig * (w[j] + beta * pe.wire_sigma_evals[j] + gamma) % r
+        terms.append((-csig * alpha_base % r, pk.sigmas[W - 1], n))
+        lin_share = lincomb(terms, n + 3)
 
-        tick("r4_lin_poly")
-        # ---- Round 5 (prover.rs:356-413, 470-488): batched opening quotients
+        # ---- Round 5: this rank's share of the two batched opening polynomials; division by (X - z) is linear too
         v = tr.get_challenge(b"v")
-        polys = [(lin_poly, n + 3)] + at_zeta
-        vs, cur = [], 1
-        for _ in polys:
-            vs.append(cur)
+        cur = pow(v, 1 + me * (2 * W - 1), r)
+        open_terms = [(1, lin_share, n + 3)]
+        for p, k in at_zeta:
+            open_terms.append((cur, p, k))
             cur = cur * v % r
-        open_poly = torch.zeros(l4, dtype=torch.int64, device="cuda")
-        L.poly_lincomb_device(c, [p.data_ptr() for p, _ in polys], [k for _, k in polys], mont(vs), open_poly.data_ptr(),
-                              n + 3, stream=st)
+        open_share = lincomb(open_terms, n + 3)
+        shifted_share = lincomb([(pow(v, me, r), perm_poly, n + 3)], n + 3)
         wpoly = torch.zeros(2, l4, dtype=torch.int64, device="cuda")
-        L.poly_divide_linear_device(c, open_poly.data_ptr(), n + 3, mont([zeta])[0], wpoly[0].data_ptr(), stream=st)
-        L.poly_divide_linear_device(c, perm_poly.data_ptr(), n + 3, mont([zeta_omega])[0], wpoly[1].data_ptr(), stream=st)
-        tick("r5_open_polys")
-        opening_proof, shifted_opening_proof = commit([wpoly[0][4:], wpoly[1][4:]], [n + 2, n + 2])
-        tick("r5_commit")
-
-        return Proof(c, wires_poly_comms, prod_perm_poly_comm, split_quot_poly_comms, opening_proof,
-                     shifted_opening_proof, wires_evals, wire_sigma_evals, perm_next_eval)
+        L.poly_divide_linear_device(c, open_share.data_ptr(), n + 3, zm, wpoly[0].data_ptr(), stream=st)
+        L.poly_divide_linear_device(c, shifted_share.data_ptr(), n + 3, zom, wpoly[1].data_ptr(), stream=st)
+        opening_proof, shifted_opening_proof = aggregated_commit([wpoly[0][4:], wpoly[1][4:]], [n + 2, n + 2])
+        return BatchProof(c, wires_poly_comms_vec, prod_perm_poly_comms_vec, poly_evals_vec, split_quot_poly_comms,
+                          opening_proof, shifted_opening_proof)

@@ -283,6 +283,48 @@ def ser_proof(cv: R.Curve, proof: dict) -> bytes:
     return bytes(out)
 
 
+def ser_batch_proof(cv: R.Curve, bp: dict) -> bytes:
+    """CanonicalSerialize (compressed) of `BatchProof` (plonk/src/proof_system/structs.rs:227-249), TurboPlonk
+    instances (plookup_proofs_vec = [None; k])"""
+    out = bytearray()
+
+    def vec_g1(v):
+        out.extend(len(v).to_bytes(8, "little"))
+        for P in v:
+            out.extend(ser_g1(cv, P))
+
+    def vec_fr(v):
+        out.extend(len(v).to_bytes(8, "little"))
+        for x in v:
+            out.extend(ser_fr(cv, x))
+
+    k = len(bp["prod_perm_poly_comms_vec"])
+    out.extend(k.to_bytes(8, "little"))
+    for comms in bp["wires_poly_comms_vec"]:
+        vec_g1(comms)
+    vec_g1(bp["prod_perm_poly_comms_vec"])
+    out.extend(k.to_bytes(8, "little"))
+    for ev in bp["poly_evals_vec"]:
+        vec_fr(ev["wires_evals"])
+        vec_fr(ev["wire_sigma_evals"])
+        out.extend(ser_fr(cv, ev["perm_next_eval"]))
+    out.extend(k.to_bytes(8, "little"))
+    out.extend(b"\x00" * k)  # plookup_proofs_vec: None each
+    vec_g1(bp["split_quot_poly_comms"])
+    out.extend(ser_g1(cv, bp["opening_proof"]))
+    out.extend(ser_g1(cv, bp["shifted_opening_proof"]))
+    return bytes(out)
+
+
+def batch_proof_from_proof(proof: dict) -> dict:
+    """impl From<Proof> for BatchProof (structs.rs:275-287)"""
+    return {"wires_poly_comms_vec": [proof["wires_poly_comms"]], "prod_perm_poly_comms_vec": [proof["prod_perm_poly_comm"]],
+            "poly_evals_vec": [{"wires_evals": proof["wires_evals"], "wire_sigma_evals": proof["wire_sigma_evals"],
+                                "perm_next_eval": proof["perm_next_eval"]}],
+            "split_quot_poly_comms": proof["split_quot_poly_comms"], "opening_proof": proof["opening_proof"],
+            "shifted_opening_proof": proof["shifted_opening_proof"]}
+
+
 # ------------------------------------------------------------------------------------------------
 # circuit
 # ------------------------------------------------------------------------------------------------
@@ -655,6 +697,146 @@ def prove(cv: R.Curve, rng, cs: PlonkCircuit, pk: dict, extra_msg: bytes | None 
     return proof, challenges, oracles
 
 
+def batch_prove(cv: R.Curve, rng, circuits, pks, extra_msg: bytes | None = None):
+    """PlonkKzgSnark::batch_prove for k TurboPlonk instances -> one BatchProof (snark.rs:61-74 -> 163-430): per round
+    the instances run in order on the ONE rng and the ONE transcript; the quotient is sum_i alpha^(3i) t_i
+    (prover.rs:519-656), the opening polynomials fold all instances (prover.rs:356-413)."""
+    r = cv.fr.p
+    if not circuits:
+        raise ValueError("zero number of circuits/proving keys")
+    if len(circuits) != len(pks):
+        raise ValueError("the number of circuits %d != the number of proving keys %d" % (len(circuits), len(pks)))
+    n, log_n, W = circuits[0].n, circuits[0].log_n, circuits[0].num_wire_types
+    for cs, pk in zip(circuits, pks):
+        if cs.n != n:
+            raise ValueError("circuit domain size %d != expected domain size %d" % (cs.n, n))
+        if pk["vk"]["domain_size"] != n:
+            raise ValueError("proving key domain size %d != expected domain size %d" % (pk["vk"]["domain_size"], n))
+    srs = pks[0]["srs"]
+    m = 1
+    while m < n * ((W * (n + 1) + 2) // n + 1):
+        m <<= 1
+    log_m = m.bit_length() - 1
+    gen = cv.fr_generator
+    g = R.domain_root(cv, log_n)
+    tr = StandardTranscript(cv)
+    if extra_msg is not None:
+        tr.append_message(b"extra info", extra_msg)
+    for cs, pk in zip(circuits, pks):
+        tr.append_vk_and_pub_input(pk["vk"], cs.public_input())
+    # Round 1
+    wire_polys_v, pub_polys_v, wires_comms_v = [], [], []
+    for cs, pk in zip(circuits, pks):
+        wp = [_mask(cv, rng, R.ifft(cv, v, log_n), n, 1) for v in cs.wire_values()]
+        comms = [_commit(cv, pk["srs"], p) for p in wp]
+        wire_polys_v.append(wp)
+        pub_polys_v.append(R.ifft(cv, cs.pub_input_values(), log_n))
+        tr.append_commitments(b"witness_poly_comms", comms)
+        wires_comms_v.append(comms)
+    # Round 2
+    beta = tr.get_challenge(b"beta")
+    gamma = tr.get_challenge(b"gamma")
+    perm_polys_v, perm_comms_v = [], []
+    for cs, pk in zip(circuits, pks):
+        z = _mask(cv, rng, R.ifft(cv, cs.prod_permutation_values(beta, gamma), log_n), n, 2)
+        c = _commit(cv, pk["srs"], z)
+        tr.append_commitments(b"perm_poly_comms", [c])
+        perm_polys_v.append(z)
+        perm_comms_v.append(c)
+    # Round 3
+    alpha = tr.get_challenge(b"alpha")
+    alpha_3 = pow(alpha, 3, r)
+    quot_evals = [0] * m
+    alpha_base = 1
+    for i, (cs, pk) in enumerate(zip(circuits, pks)):
+        sel_c = [R.fft(cv, p, log_m, gen) for p in pk["selectors"]]
+        sig_c = [R.fft(cv, p, log_m, gen) for p in pk["sigmas"]]
+        wir_c = [R.fft(cv, p, log_m, gen) for p in wire_polys_v[i]]
+        z_c = R.fft(cv, perm_polys_v[i], log_m, gen)
+        pi_c = R.fft(cv, pub_polys_v[i], log_m, gen)
+        ev = R.quotient_evals_turbo(cv, log_n, log_m, sel_c, sig_c, wir_c, z_c, pi_c, cs.k, alpha, beta, gamma, alpha_base)
+        quot_evals = [(a + b) % r for a, b in zip(quot_evals, ev)]
+        alpha_base = alpha_base * alpha_3 % r
+    quot = R.ifft(cv, quot_evals, log_m, gen)
+    while quot and quot[-1] == 0:
+        quot.pop()
+    expected_degree = W * (n + 1) + 2
+    if len(quot) - 1 != expected_degree:
+        raise ValueError("WrongQuotientPolyDegree(%d, %d)" % (len(quot) - 1, expected_degree))
+    split = []
+    for i in range(W):
+        end = (i + 1) * (n + 2) if i < W - 1 else len(quot)
+        split.append(quot[i * (n + 2):end])
+    last = 0
+    for i in range(W - 1):
+        now = fr_rand(cv, rng)
+        split[i][0] = (split[i][0] - last) % r
+        split[i].append(now)
+        last = now
+    split[W - 1][0] = (split[W - 1][0] - last) % r
+    split_quot_poly_comms = [_commit(cv, srs, p) for p in split]
+    tr.append_commitments(b"quot_poly_comms", split_quot_poly_comms)
+    # Round 4
+    zeta = tr.get_challenge(b"zeta")
+    evals_v = []
+    for i, pk in enumerate(pks):
+        ev = {"wires_evals": [R.poly_eval(cv, p, zeta) for p in wire_polys_v[i]],
+              "wire_sigma_evals": [R.poly_eval(cv, p, zeta) for p in pk["sigmas"][:W - 1]],
+              "perm_next_eval": R.poly_eval(cv, perm_polys_v[i], zeta * g % r)}
+        tr.append_field_elems(b"wire_evals", ev["wires_evals"])
+        tr.append_field_elems(b"wire_sigma_evals", ev["wire_sigma_evals"])
+        tr.append_field_elems(b"perm_next_eval", [ev["perm_next_eval"]])
+        evals_v.append(ev)
+    vanish_eval = (pow(zeta, n, r) - 1) % r
+    zeta_n2 = (vanish_eval + 1) * zeta % r * zeta % r
+    lagrange_1 = vanish_eval * pow(n * (zeta - 1), -1, r) % r
+    terms = []
+    coeff = 1
+    for i, t in enumerate(split):
+        if i:
+            coeff = coeff * zeta_n2 % r
+        terms.append((-vanish_eval * coeff, t))
+    alpha_base = 1
+    for i, pk in enumerate(pks):
+        w, sig_e, znext = evals_v[i]["wires_evals"], evals_v[i]["wire_sigma_evals"], evals_v[i]["perm_next_eval"]
+        q_scalars = [w[0], w[1], w[2], w[3], w[0] * w[1], w[2] * w[3], pow(w[0], 5, r), pow(w[1], 5, r), pow(w[2], 5, r),
+                     pow(w[3], 5, r), -w[4], 1, w[0] * w[1] * w[2] * w[3] * w[4]]
+        terms += [(alpha_base * s, p) for s, p in zip(q_scalars, pk["selectors"])]
+        c_z = alpha
+        for j in range(W):
+            c_z = c_z * (w[j] + beta * pk["vk"]["k"][j] % r * zeta + gamma) % r
+        c_z = (c_z + alpha * alpha % r * lagrange_1) % r
+        terms.append((alpha_base * c_z, perm_polys_v[i]))
+        c_s = alpha * beta % r * znext % r
+        for j in range(W - 1):
+            c_s = c_s * (w[j] + beta * sig_e[j] + gamma) % r
+        terms.append((-c_s * alpha_base, pk["sigmas"][W - 1]))
+        alpha_base = alpha_base * alpha_3 % r
+    lin_poly = _lincomb(r, terms, n + 3)
+    # Round 5
+    v = tr.get_challenge(b"v")
+    polys = [lin_poly]
+    for i, pk in enumerate(pks):
+        polys += wire_polys_v[i] + pk["sigmas"][:W - 1]
+    batch, c = [], 1
+    for p in polys:
+        batch.append((c, p))
+        c = c * v % r
+    q, _ = R.witness_poly(cv, _lincomb(r, batch, n + 3), zeta)
+    opening_proof = _commit(cv, srs, q)
+    batch, c = [], 1
+    for z in perm_polys_v:
+        batch.append((c, z))
+        c = c * v % r
+    q, _ = R.witness_poly(cv, _lincomb(r, batch, n + 3), zeta * g % r)
+    shifted_opening_proof = _commit(cv, srs, q)
+    bp = {"wires_poly_comms_vec": wires_comms_v, "prod_perm_poly_comms_vec": perm_comms_v, "poly_evals_vec": evals_v,
+          "split_quot_poly_comms": split_quot_poly_comms, "opening_proof": opening_proof,
+          "shifted_opening_proof": shifted_opening_proof}
+    challenges = {"beta": beta, "gamma": gamma, "alpha": alpha, "zeta": zeta, "v": v}
+    return bp, challenges
+
+
 # ------------------------------------------------------------------------------------------------
 # verifier
 # ------------------------------------------------------------------------------------------------
@@ -751,5 +933,109 @@ def verify(cv: R.Curve, vk: dict, pub_input, proof: dict, extra_msg: bytes | Non
     B = R.msm_naive(cv, [c for _, c in sb], [s for s, _ in sb])
     if pairing_check is not None:
         return pairing_check(A, vk["beta_h"], B, vk["h"])
+    assert trapdoor_beta is not None
+    return R.ec_mul(cv, trapdoor_beta, A) == B
+
+
+def verify_batch_proof(cv: R.Curve, vks, pub_inputs, bp: dict, extra_msg: bytes | None = None,
+                       trapdoor_beta: int | None = None, pairing_check=None) -> bool:
+    """Verifier::prepare_pcs_info + batch_verify_opening_proofs for ONE BatchProof over k TurboPlonk instances
+    (verifier.rs:70-257, 262-339, 358-432, 439-535, 541-713, 718-788).  Final pairing check as in verify()."""
+    r = cv.fr.p
+    k_inst = len(bp["prod_perm_poly_comms_vec"])
+    if not (len(vks) == k_inst == len(pub_inputs)) or k_inst == 0:
+        return False
+    n = vks[0]["domain_size"]
+    log_n = n.bit_length() - 1
+    for vk, pi in zip(vks, pub_inputs):
+        if len(pi) != vk["num_inputs"] or vk["domain_size"] != n:
+            return False
+    pts = bp["split_quot_poly_comms"] + bp["prod_perm_poly_comms_vec"] + [bp["opening_proof"], bp["shifted_opening_proof"]]
+    for comms in bp["wires_poly_comms_vec"]:
+        pts = pts + comms
+    if not all(R.on_curve(cv, P) for P in pts):
+        return False
+    tr = StandardTranscript(cv)
+    if extra_msg is not None:
+        tr.append_message(b"extra info", extra_msg)
+    for vk, pi in zip(vks, pub_inputs):
+        tr.append_vk_and_pub_input(vk, pi)
+    for comms in bp["wires_poly_comms_vec"]:
+        tr.append_commitments(b"witness_poly_comms", comms)
+    beta = tr.get_challenge(b"beta")
+    gamma = tr.get_challenge(b"gamma")
+    tr.append_commitments(b"perm_poly_comms", bp["prod_perm_poly_comms_vec"])
+    alpha = tr.get_challenge(b"alpha")
+    tr.append_commitments(b"quot_poly_comms", bp["split_quot_poly_comms"])
+    zeta = tr.get_challenge(b"zeta")
+    for ev in bp["poly_evals_vec"]:
+        tr.append_field_elems(b"wire_evals", ev["wires_evals"])
+        tr.append_field_elems(b"wire_sigma_evals", ev["wire_sigma_evals"])
+        tr.append_field_elems(b"perm_next_eval", [ev["perm_next_eval"]])
+    v = tr.get_challenge(b"v")
+    tr.append_commitments(b"open_proof", [bp["opening_proof"]])
+    tr.append_commitments(b"shifted_open_proof", [bp["shifted_opening_proof"]])
+    u = tr.get_challenge(b"u")
+
+    g = R.domain_root(cv, log_n)
+    alpha_2 = alpha * alpha % r
+    alpha_3 = alpha_2 * alpha % r
+    alpha_bases = [pow(alpha_3, i, r) for i in range(k_inst)]
+    vanish_eval = (pow(zeta, n, r) - 1) % r
+    lagrange_1 = vanish_eval * pow(n * (zeta - 1), -1, r) % r
+    lin_poly_constant = 0
+    sb = []
+    for i, (vk, pi) in enumerate(zip(vks, pub_inputs)):
+        ev = bp["poly_evals_vec"][i]
+        w, sig, znext = ev["wires_evals"], ev["wire_sigma_evals"], ev["perm_next_eval"]
+        W = len(w)
+        ab = alpha_bases[i]
+        pi_eval = 0
+        gi = 1
+        for x in pi:
+            pi_eval = (pi_eval + vanish_eval * gi % r * pow(n * (zeta - gi), -1, r) % r * x) % r
+            gi = gi * g % r
+        tmp = (pi_eval - alpha_2 * lagrange_1) % r
+        acc = alpha * znext % r * (gamma + w[W - 1]) % r
+        for we, se in zip(w[:W - 1], sig):
+            acc = acc * (gamma + we + beta * se) % r
+        lin_poly_constant = (lin_poly_constant + ab * (tmp - acc)) % r
+        coeff = alpha_2 * lagrange_1 % r
+        acc = alpha
+        for we, kk in zip(w, vk["k"]):
+            acc = acc * (beta * kk % r * zeta + gamma + we) % r
+        sb.append(((coeff + acc) * ab % r, bp["prod_perm_poly_comms_vec"][i]))
+        acc = alpha * beta % r * znext % r
+        for we, se in zip(w[:W - 1], sig):
+            acc = acc * (beta * se + gamma + we) % r
+        sb.append((-acc * ab % r, vk["sigma_comms"][-1]))
+        q_scalars = [w[0], w[1], w[2], w[3], w[0] * w[1], w[2] * w[3], pow(w[0], 5, r), pow(w[1], 5, r),
+                     pow(w[2], 5, r), pow(w[3], 5, r), -w[4], 1, w[0] * w[1] * w[2] * w[3] * w[4]]
+        sb += [(s * ab % r, c) for s, c in zip(q_scalars, vk["selector_comms"])]
+    zeta_n2 = (1 + vanish_eval) * zeta % r * zeta % r
+    coeff = -vanish_eval % r
+    sb.append((coeff, bp["split_quot_poly_comms"][0]))
+    for c in bp["split_quot_poly_comms"][1:]:
+        coeff = coeff * zeta_n2 % r
+        sb.append((coeff, c))
+    v_base, uv_base = v, u
+    result = -lin_poly_constant % r
+    for i, vk in enumerate(vks):
+        ev = bp["poly_evals_vec"][i]
+        W = len(bp["wires_poly_comms_vec"][i])
+        for c, e in zip(bp["wires_poly_comms_vec"][i] + vk["sigma_comms"][:W - 1], ev["wires_evals"] + ev["wire_sigma_evals"]):
+            sb.append((v_base, c))
+            result = (result + e * v_base) % r
+            v_base = v_base * v % r
+        sb.append((uv_base, bp["prod_perm_poly_comms_vec"][i]))
+        result = (result + ev["perm_next_eval"] * uv_base) % r
+        uv_base = uv_base * v % r
+    A = R.msm_naive(cv, [bp["opening_proof"], bp["shifted_opening_proof"]], [1, u])
+    sb.append((zeta, bp["opening_proof"]))
+    sb.append((u * (zeta * g % r) % r, bp["shifted_opening_proof"]))
+    sb.append((-result % r, vks[0]["g"]))
+    B = R.msm_naive(cv, [c for _, c in sb], [s for s, _ in sb])
+    if pairing_check is not None:
+        return pairing_check(A, vks[0]["beta_h"], B, vks[0]["h"])
     assert trapdoor_beta is not None
     return R.ec_mul(cv, trapdoor_beta, A) == B

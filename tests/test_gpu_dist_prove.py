@@ -176,3 +176,54 @@ def test_sharded_real_prove_is_byte_identical(world, size):
     for p in procs:
         p.join(timeout=30)
     assert sorted(res) == [(r, True) for r in range(world)], res
+
+
+def _real_batch_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from jellyfish_amd import lib as L
+        from jellyfish_amd import plonk as JP
+        from tests.test_gpu_plonk import BETA, build
+
+        torch.cuda.set_device(0)
+        L.load_library()
+        L.init(0)
+        sizes = [60, 80, 100, 70][:world]
+        css = [build(JP.PlonkCircuit(0), s) for s in sizes]
+        srs = JP.PlonkKzgSnark.universal_setup_for_testing(0, css[0].eval_domain_size() + 2, BETA)
+        keys = [JP.PlonkKzgSnark.preprocess(srs, c) for c in css]
+        ref = JP.PlonkKzgSnark.batch_prove(JP.H.test_rng(), css, [k[0] for k in keys], b"cfg5").serialize_compressed()
+        got = JP.PlonkKzgSnark.batch_prove_one_per_rank(JP.H.test_rng(), css[rank], keys[rank][0], b"cfg5")
+        keys[rank][0].keep_coset_evals()
+        kept = JP.PlonkKzgSnark.batch_prove_one_per_rank(JP.H.test_rng(), css[rank], keys[rank][0], b"cfg5")
+        q.put((rank, ref == got.serialize_compressed() and ref == kept.serialize_compressed() and len(got) == world))
+    except Exception as e:
+        import traceback
+
+        q.put((rank, repr(e) + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_real_batch_prove_one_circuit_per_rank_is_byte_identical(world):
+    """PlonkKzgSnark.batch_prove_one_per_rank (BASELINE config 5's layout: one circuit per GPU, here the ranks share
+    cuda:0): every rank returns the BatchProof that batch_prove of all the circuits gives on one GPU from the same RNG
+    state -- per-instance commitments / evaluations gathered, aggregated commitments as group sums of per-rank shares."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_real_batch_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=30)
+    assert sorted(res) == [(r, True) for r in range(world)], res

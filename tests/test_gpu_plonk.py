@@ -115,3 +115,72 @@ def test_bench_circuit_proof_verifies(hip, log_gates):
     assert len(proof.serialize_compressed()) == 769
     pk.keep_coset_evals()
     assert JP.PlonkKzgSnark.prove(JP.H.test_rng(), cs, pk).serialize_compressed() == proof.serialize_compressed()
+
+
+@pytest.mark.parametrize("cv", [R.BN254, R.BLS12_381], ids=lambda c: c.name)
+def test_batch_prove_matches_oracle_and_verifies(hip, cv):
+    """PlonkKzgSnark::batch_prove (snark.rs:61-74 -> 163-430; the reference's test_key_aggregation_and_batch_prove
+    :1567-1721 protocol): 3 different circuits of one domain size -> ONE BatchProof, byte-identical to the restated
+    prover on the same RNG stream, accepted by the restated batch verifier, rejected for a wrong public input or a
+    swapped instance order; one instance gives the bytes of prove() (impl From<Proof> for BatchProof)."""
+    from jellyfish_amd import plonk as JP
+
+    sizes = [60, 80, 100]
+    ocss = [build(P.PlonkCircuit(cv), s) for s in sizes]
+    css = [build(JP.PlonkCircuit(cv.curve_id), s) for s in sizes]
+    n = css[0].eval_domain_size()
+    assert all(c.eval_domain_size() == n for c in css) and all(o.n == n for o in ocss)
+    beta = BETA % cv.fr.p
+    osrs = P.universal_setup_for_testing(cv, n + 2, beta)
+    srs = JP.PlonkKzgSnark.universal_setup_for_testing(cv.curve_id, n + 2, beta)
+    okeys = [P.preprocess(cv, osrs, o) for o in ocss]
+    keys = [JP.PlonkKzgSnark.preprocess(srs, c) for c in css]
+    pks, vks = [k[0] for k in keys], [k[1].as_dict() for k in keys]
+    pubs = [c.public_input() for c in css]
+
+    bp = JP.PlonkKzgSnark.batch_prove(JP.H.test_rng(), css, pks, extra_transcript_init_msg=b"batch")
+    obp, _ = P.batch_prove(cv, P.test_rng(), ocss, [k[0] for k in okeys], extra_msg=b"batch")
+    assert len(bp) == 3
+    assert bp.as_dict() == obp
+    assert bp.serialize_compressed() == P.ser_batch_proof(cv, obp)
+    assert P.verify_batch_proof(cv, vks, pubs, bp.as_dict(), extra_msg=b"batch", trapdoor_beta=beta)
+    assert not P.verify_batch_proof(cv, vks, pubs, bp.as_dict(), trapdoor_beta=beta)
+    bad = [list(p) for p in pubs]
+    bad[1][0] = (bad[1][0] + 1) % cv.fr.p
+    assert not P.verify_batch_proof(cv, vks, bad, bp.as_dict(), extra_msg=b"batch", trapdoor_beta=beta)
+    assert not P.verify_batch_proof(cv, vks[::-1], pubs[::-1], bp.as_dict(), extra_msg=b"batch", trapdoor_beta=beta)
+    # proving-key-resident coset evaluations on some instances only: same bytes
+    pks[1].keep_coset_evals()
+    again = JP.PlonkKzgSnark.batch_prove(JP.H.test_rng(), css, pks, extra_transcript_init_msg=b"batch")
+    assert again.serialize_compressed() == bp.serialize_compressed()
+    # one instance: the BatchProof of prove()'s Proof
+    one = JP.PlonkKzgSnark.batch_prove(JP.H.test_rng(), css[:1], pks[:1])
+    single = JP.PlonkKzgSnark.prove(JP.H.test_rng(), css[0], pks[0])
+    assert one.to_proof().serialize_compressed() == single.serialize_compressed()
+    assert one.as_dict() == P.batch_proof_from_proof(single.as_dict())
+    assert P.verify_batch_proof(cv, vks[:1], pubs[:1], one.as_dict(), trapdoor_beta=beta)
+    assert P.verify(cv, vks[0], pubs[0], single.as_dict(), trapdoor_beta=beta)
+    with pytest.raises(JP.PlonkError, match="number of circuits"):
+        JP.PlonkKzgSnark.batch_prove(JP.H.test_rng(), css, pks[:2])
+    with pytest.raises(JP.PlonkError, match="zero number"):
+        JP.PlonkKzgSnark.batch_prove(JP.H.test_rng(), [], [])
+
+
+def test_batch_prove_bench_circuits_verifies(hip):
+    """4 instances of the bench circuit at 2^16 gates (BN254): the aggregated proof verifies (size-independent property)"""
+    from jellyfish_amd import plonk as JP
+
+    cv = R.BN254
+    css = []
+    for k in range(4):
+        cs = JP.PlonkCircuit.new_turbo_plonk(0)
+        a = cs.create_variable(k + 2)
+        for _ in range((1 << 16) - 10):
+            a = cs.add(a, cs.one())
+        cs.finalize_for_arithmetization()
+        css.append(cs)
+    n = css[0].eval_domain_size()
+    srs = JP.PlonkKzgSnark.universal_setup_for_testing(0, n + 2, BETA)
+    keys = [JP.PlonkKzgSnark.preprocess(srs, c) for c in css]
+    bp = JP.PlonkKzgSnark.batch_prove(JP.H.test_rng(), css, [k[0] for k in keys])
+    assert P.verify_batch_proof(cv, [k[1].as_dict() for k in keys], [[]] * 4, bp.as_dict(), trapdoor_beta=BETA)
