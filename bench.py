@@ -68,6 +68,14 @@ def uniform_fr(n: int, seed: int, modulus: int) -> np.ndarray:
         out[bad] = fresh
 
 
+def max_over_ranks(torch, dist, dt: float) -> float:
+    """MAX over ranks of a wall time (device tensor for RCCL, host tensor for the gloo rehearsal)"""
+    dev = "cpu" if dist.get_backend() == "gloo" else "cuda"
+    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    return float(tt.item())
+
+
 def prove_section(L, torch, dist, world, stream, beta):
     """Device-side operation sequence of one TurboPlonk proof, 2^20 gates, BN254 (BASELINE config 4 shape); host
     transcript / RNG / grand product are inputs (jellyfish_amd/prover_path.py).  world > 1: MSM point ranges sharded
@@ -92,9 +100,7 @@ def prove_section(L, torch, dist, world, stream, beta):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         if world > 1:
-            tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt = float(tt.item())
+            dt = max_over_ranks(torch, dist, dt)
         ts.append(dt * 1e3)
     sec = {
         "workload": "TurboPlonk BN254 2^20 gates, one instance: 7 iNTT(2^20) + 25 coset NTT(2^23, zero-extended) "
@@ -151,9 +157,7 @@ def real_prove_section(L, torch, dist, world, log_g=20):
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             if world > 1:
-                tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                dt = float(tt.item())
+                dt = max_over_ranks(torch, dist, dt)
             ts.append(dt * 1e3)
         return ts
 
@@ -237,9 +241,7 @@ def real_batch_prove_section(L, torch, dist, world, rank, log_g=20):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         if world > 1:
-            tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt = float(tt.item())
+            dt = max_over_ranks(torch, dist, dt)
         ts.append(dt * 1e3)
     ms = float(np.median(ts))
     sec = {"workload": "PlonkKzgSnark::batch_prove, %d TurboPlonk BN254 bench circuits of 2^%d gates -> one BatchProof, "
@@ -293,9 +295,7 @@ def batch_prove_section(L, torch, dist, world, rank, stream, log_g):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         if world > 1:
-            tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt = float(tt.item())
+            dt = max_over_ranks(torch, dist, dt)
         ts.append(dt * 1e3)
     sec = {"workload": "batch_prove, %d UltraPlonk (Plookup) BLS12-381 circuits of 2^%d gates, one per GPU: per circuit "
                        "11 iNTT(n) + 35 coset NTT(8n) + 2 grand products + Plookup quotient + coset iNTT(8n) + 18 commitments + 27 evaluations"
@@ -333,9 +333,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # JF_BENCH_REHEARSE=1: all ranks share cuda:0 and rendezvous over gloo (a one-GPU box rehearsing the N > 1 code path;
+    # RCCL refuses two ranks on one device).  Never set by the driver.
+    rehearse = world > 1 and os.environ.get("JF_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     if world > 1:
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
     L.load_library()
@@ -383,9 +391,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        elapsed = max_over_ranks(torch, dist, elapsed)
     result_bytes = bytes(res.cpu().numpy().tobytes())
 
     out = None
@@ -568,37 +574,60 @@ def main():
             except Exception as e:  # the baseline is reporting only; never fail the bench on it
                 out["cpu_baseline"] = {"value": None, "unit": "Mpts/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
 
+    # The secondary sections below run collectives at N > 1: if they stall (a rank failing inside a collective leaves
+    # the others waiting), a watchdog still prints the headline line measured above, marks what is missing and ends
+    # the process, so the contract's ONE JSON line is never lost to a secondary measurement.
+    import copy
+    import threading
+
+    finished = threading.Event()
+    snapshot = {"out": copy.deepcopy(out)}
+
+    def watchdog():
+        if finished.wait(float(os.environ.get("JF_BENCH_SECONDARY_TIMEOUT_S", "600"))):
+            return
+        if rank == 0 and snapshot["out"] is not None:
+            line = snapshot["out"]
+            line["secondary_sections"] = "timed out; sections not listed here did not finish"
+            print(json.dumps(line), flush=True)
+        os._exit(0)
+
+    if world > 1:
+        threading.Thread(target=watchdog, daemon=True).start()
+
+    def keep(key, sec):
+        if rank == 0:
+            out[key] = sec
+            snapshot["out"] = copy.deepcopy(out)
+
     if world > 1 and not args.no_prove:
         # BASELINE config 4 at N GPUs: every commitment's point range is partitioned over the ranks
         try:
             sec = real_prove_section(L, torch, dist, world)
         except Exception as e:  # never lose the headline line to the secondary measurement
             sec = {"error": repr(e)}
-        if rank == 0:
-            out["plonk_prove"] = sec
+        keep("plonk_prove", sec)
         try:
             sec = prove_section(L, torch, dist, world, stream, beta)
         except Exception as e:
             sec = {"error": repr(e)}
-        if rank == 0:
-            out["plonk_prove_hot_path"] = sec
+        keep("plonk_prove_hot_path", sec)
 
     if not args.no_prove:
         try:
             sec = real_batch_prove_section(L, torch, dist, world, rank)
         except Exception as e:
             sec = {"error": repr(e)}
-        if rank == 0:
-            out["batch_prove"] = sec
+        keep("batch_prove", sec)
 
     if args.ultra_log_n:
         try:
             sec = batch_prove_section(L, torch, dist, world, rank, stream, args.ultra_log_n)
         except Exception as e:
             sec = {"error": repr(e)}
-        if rank == 0:
-            out["batch_prove_ultra"] = sec
+        keep("batch_prove_ultra", sec)
 
+    finished.set()
     if rank == 0:
         print(json.dumps(out), flush=True)
     srs.free()
