@@ -682,13 +682,7 @@ class PlonkKzgSnark:
                 PROFILE[name] = round(PROFILE.get(name, 0.0) + (now - t_last[0]) * 1e3, 3)
                 t_last[0] = now
 
-        tr = StandardTranscript(cp)
-        if extra_transcript_init_msg is not None:
-            tr.append_message(b"extra info", extra_transcript_init_msg)
         pub_inputs = [circuit.public_input() for circuit in circuits]
-        for pk, pub_input in zip(prove_keys, pub_inputs):
-            tr.append_vk_and_pub_input(pk.vk, pub_input)
-        tick("transcript_init")
 
         def mask(poly: torch.Tensor, hiding_bound: int):
             """mask_polynomial (prover.rs:457-466): + (b_0 + .. + b_h X^h)(X^n - 1); poly has room for n + h + 1"""
@@ -716,7 +710,7 @@ class PlonkKzgSnark:
         # ---- Round 1 (prover.rs:77-91): wire polynomials, public-input polynomial; instances in order
         ln = n + 3
         l4 = ln * 4
-        wire_vals_v, wire_polys_v, pub_poly_v, wires_poly_comms_vec = [], [], [], []
+        wire_vals_v, wire_polys_v, pub_poly_v, wires_poly_comms_vec, bufs = [], [], [], [], []
         for i, (circuit, pk) in enumerate(zip(circuits, prove_keys)):
             wm = witness_monts[i] if witness_monts is not None and witness_monts[i] is not None else mont(circuit.witness)
             wit = _dev_fr(wm).view(-1, 4)
@@ -727,7 +721,17 @@ class PlonkKzgSnark:
             if pub_inputs[i]:
                 buf[W, :4 * len(pub_inputs[i])] = _dev_fr(mont(pub_inputs[i]))   # io gates sit in rows 0 .. num_inputs-1
             L.ntt_device(c, buf.data_ptr(), log_n, W + 1, inverse=True, stream=st)
-            tick("r1_gather_intt")
+            wire_vals_v.append(wire_vals)
+            bufs.append(buf)
+        # the transcript is initialised (snark.rs:231-237) while the device runs the witness gather and the iNTTs
+        tr = StandardTranscript(cp)
+        if extra_transcript_init_msg is not None:
+            tr.append_message(b"extra info", extra_transcript_init_msg)
+        for pk, pub_input in zip(prove_keys, pub_inputs):
+            tr.append_vk_and_pub_input(pk.vk, pub_input)
+        tick("r1_gather_intt_transcript_init")
+        for i, (circuit, pk) in enumerate(zip(circuits, prove_keys)):
+            buf = bufs[i]
             wire_polys = torch.zeros(W, l4, dtype=torch.int64, device="cuda")
             wire_polys[:, :n4].copy_(buf[:W])
             # mask_polynomial for the W wire polynomials with ONE read-back and two uploads (RNG draws in the
@@ -740,10 +744,10 @@ class PlonkKzgSnark:
             comms = commits[i]([wire_polys[j] for j in range(W)], [n + 2] * W)
             tr.append_commitments(b"witness_poly_comms", comms)
             tick("r1_commit")
-            wire_vals_v.append(wire_vals)
             wire_polys_v.append(wire_polys)
             pub_poly_v.append(buf[W])
             wires_poly_comms_vec.append(comms)
+        del bufs
 
         # ---- Round 2 (prover.rs:128-142; grand product constraint_system.rs:1394-1420)
         beta = tr.get_challenge(b"beta")
@@ -846,24 +850,29 @@ class PlonkKzgSnark:
             unshard_quotient(cp, c, gathered, m, quot, st)
         tick("r3_quotient_intt")
         expected_degree = W * (n + 1) + 2
-        tail_nonzero = bool(torch.any(quot[(expected_degree + 1) * 4:] != 0).item())
-        top_zero = not bool(torch.any(quot[expected_degree * 4:(expected_degree + 1) * 4] != 0).item())
-        if tail_nonzero or top_zero:
-            raise PlonkError("WrongQuotientPolyDegree(expected %d)" % expected_degree)
+        # the split randomisers (prover.rs:926-940) are drawn while the device still works on the quotient: the next RNG
+        # draws in the reference's order whether or not the degree check below passes
+        randomizers = [H.fr_rand(cp, rng) for _ in range(W - 1)]
+        randomizers_dev = _dev_fr(mont(randomizers)).view(W - 1, 4)
         split = torch.zeros(W, l4, dtype=torch.int64, device="cuda")
         step = (n + 2) * 4
         for i in range(W - 1):
             split[i, :step].copy_(quot[i * step:(i + 1) * step])
         last_len = expected_degree + 1 - (W - 1) * (n + 2)
         split[W - 1, :last_len * 4].copy_(quot[(W - 1) * step:(expected_degree + 1) * 4])
+        split[:W - 1, step:step + 4] = randomizers_dev
+        # ONE read-back: [tail non-zero flag, top coefficient, first coefficient of every piece]
+        flag = torch.any(quot[(expected_degree + 1) * 4:] != 0).to(torch.int64).view(1)
+        back = torch.cat([flag, quot[expected_degree * 4:(expected_degree + 1) * 4],
+                          split[:, :4].contiguous().view(-1)]).cpu().numpy()
         del quot
-        firsts = _read_fr(cp, split[:, :4].contiguous())
+        if back[0] != 0 or not back[1:5].any():
+            raise PlonkError("WrongQuotientPolyDegree(expected %d)" % expected_degree)
+        firsts = H.fr_from_mont(cp, back[5:].view(np.uint64))
         last_randomizer = 0
         for i in range(W - 1):
-            now_randomizer = H.fr_rand(cp, rng)
             firsts[i] = (firsts[i] - last_randomizer) % r
-            split[i, step:step + 4] = _dev_fr(mont([now_randomizer]))
-            last_randomizer = now_randomizer
+            last_randomizer = randomizers[i]
         firsts[W - 1] = (firsts[W - 1] - last_randomizer) % r
         split[:, :4] = _dev_fr(mont(firsts)).view(W, 4)
         split_lens = [n + 3] * (W - 1) + [last_len]
