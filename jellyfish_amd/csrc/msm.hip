@@ -304,6 +304,29 @@ __global__ __launch_bounds__(256) void k_scan_add(uint32_t* __restrict__ off, ui
     cursor[i] = v;
 }
 
+// Advance (b, b_lo, b_hi) to the bucket that holds sorted position `pos` (pos >= b_hi on entry).  The next bucket is
+// the usual answer; when it is empty the rest is a binary search, not a walk: a sparse polynomial (an unused wire is
+// four blinding coefficients among 2^20 zeros) leaves tens of thousands of empty buckets between two entries, and
+// walking them with one dependent load each cost 5.7 ms per such commitment (2 of the 5 wire polynomials of the bench
+// circuit).
+JF_DEV void next_bucket(const uint32_t* __restrict__ off, uint32_t B, uint32_t pos, uint32_t& b, uint32_t& b_lo,
+                        uint32_t& b_hi) {
+    b++;
+    b_lo = b_hi;
+    b_hi = off[b + 1];
+    if (pos < b_hi) return;
+    // largest bucket index with off[.] <= pos; off is non-decreasing and off[B] = total > pos
+    uint32_t lo = b + 1, hi = B;
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (off[mid] <= pos) lo = mid;
+        else hi = mid;
+    }
+    b = lo;
+    b_lo = off[b];
+    b_hi = off[b + 1];
+}
+
 // One lane per slice of L consecutive sorted entries.  A run (maximal stretch of one bucket
 // inside a slice) that covers its whole bucket is final and goes to buckets[b]; a run cut
 // by a slice boundary goes to partA[t] (it contains the slice's first entry) or partB[t]
@@ -362,11 +385,7 @@ __global__ __launch_bounds__(128) void k_msm_accumulate(const uint32_t* __restri
             flush(pos);
             acc = XYZZ<Cv>::identity();
             run_start = pos;
-            do {
-                b++;
-                b_lo = b_hi;
-                b_hi = off[b + 1];
-            } while (pos >= b_hi);
+            next_bucket(off, B, pos, b, b_lo, b_hi);
         }
         uint32_t e = sorted[pos];
         Affine<Cv> p = affine_load<Cv>(table + (size_t)(e & 0x7fffffffu) * PT);
@@ -512,11 +531,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
             flush(pos);
             inf = true;
             run_start = pos;
-            do {
-                b++;
-                b_lo = b_hi;
-                b_hi = off[b + 1];
-            } while (pos >= b_hi);
+            next_bucket(off, B, pos, b, b_lo, b_hi);
         }
         do {
             const uint32_t e = e_cur;
