@@ -162,6 +162,15 @@ def real_prove_section(L, torch, dist, world, log_g=20):
         return ts
 
     ts = timed()
+    # the same with every polynomial transformed, as the reference does (prover.rs:534-549): by default prove() fills the
+    # coset evaluations of identically-zero polynomials (selectors of gate kinds the circuit never uses, an empty public
+    # input) instead of transforming them -- same values, same proof bytes
+    zero_sel = int(sum(pk.selector_is_zero))
+    JP.SKIP_ZERO_POLYS = False
+    try:
+        ts_all = timed(3)
+    finally:
+        JP.SKIP_ZERO_POLYS = True
     # second mode: the proving key keeps its 18 selector / sigma coset evaluations (this rank's slice) in HBM
     rank = dist.get_rank() if world > 1 else 0
     pk.keep_coset_evals(rank=rank, world=world)
@@ -181,6 +190,12 @@ def real_prove_section(L, torch, dist, world, log_g=20):
                           "opening polynomials on every rank" % (world, world, (m // world * 32) >> 20)
                           if coset_sharded else "transforms and quotient on every rank"),
            "ms": round(float(np.median(ts)), 3), "runs_ms": [round(t, 3) for t in ts],
+           "ms_all_25_coset_ntts": round(float(np.median(ts_all)), 3),
+           "zero_polynomials": "%d of the 13 selector polynomials of this circuit are identically zero (it has addition "
+                               "and constant gates only) and the public input is empty: 'ms' fills those %d rows of coset "
+                               "evaluations with zeros instead of transforming them (same proof bytes, "
+                               "tests/test_gpu_plonk.py); 'ms_all_25_coset_ntts' transforms all of them like the reference"
+                               % (zero_sel, zero_sel + 1),
            "ms_pk_coset_evals_resident": round(float(np.median(ts_kept)), 3),
            "runs_ms_pk_coset_evals_resident": [round(t, 3) for t in ts_kept],
            "pk_coset_evals_resident": "second timing: ProvingKey.keep_coset_evals() holds the 13 selector + 5 sigma coset "

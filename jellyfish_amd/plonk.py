@@ -288,6 +288,9 @@ class ProvingKey:
     # only, and 288 GB of HBM holds them (18 x 256 MiB at n = 2^20).  Same values, so the same proof bytes.
     coset_evals: torch.Tensor = field(repr=False, default=None)
     coset_slice: tuple = (0, 1)   # (rank, world) the resident evaluations were computed for
+    # selector polynomials that are identically zero for this circuit (a gate kind it never uses): their coset
+    # evaluations are zero, so prove() fills those rows instead of transforming them (same values, same proof bytes)
+    selector_is_zero: tuple = ()
 
     def domain_size(self) -> int:
         return self.vk.domain_size
@@ -546,6 +549,29 @@ def slice_offset(cp, m: int, rank: int) -> int:
     return cp.fr_generator * pow(w_m, rank, cp.r) % cp.r
 
 
+SKIP_ZERO_POLYS = True   # False: transform every polynomial like the reference does (bench comparison; same results)
+
+
+def _coset_ntt_rows(c: int, cs: torch.Tensor, zero_rows, log_len: int, off, in_len: int, st):
+    """forward coset NTT of the rows of `cs` (one polynomial per row, first in_len coefficients set), except the rows in
+    zero_rows, which hold the zero polynomial: those are filled with zeros.  The reference transforms all of them
+    (prover.rs:534-549); an identically-zero selector (a gate kind the circuit never uses) or an empty public input has
+    zero evaluations anyway."""
+    rows = cs.shape[0]
+    zero_rows = set(zero_rows) if SKIP_ZERO_POLYS else set()
+    j = 0
+    while j < rows:
+        if j in zero_rows:
+            cs[j].zero_()
+            j += 1
+            continue
+        k = j
+        while k < rows and k not in zero_rows:
+            k += 1
+        L.ntt_device(c, cs[j].data_ptr(), log_len, k - j, inverse=False, coset_mont=off, in_len=in_len, stream=st)
+        j = k
+
+
 def unshard_coeffs(cp, m: int, G: int) -> list:
     """gathered[g] = t(X) mod (X^ml - c_g), c_g = h^ml w_G^g (rank g's coset iNTT of its slice of the quotient
     evaluations), ml = m / G.  With t = sum_c X^(c ml) t_c:  gathered[g][j] = sum_c (h^ml)^c w_G^(g c) t_c[j], a size-G DFT
@@ -611,6 +637,7 @@ class PlonkKzgSnark:
                           list(circuit.k), srs.g, srs.h, srs.beta_h)
         pk = ProvingKey(c, sigmas, selectors, srs.powers_of_g, vk, idp, sigma_vals,
                         torch.from_numpy(circuit.wire_variables.reshape(-1)).cuda())
+        pk.selector_is_zero = tuple(bool(z) for z in (~torch.any(selectors != 0, dim=1)).cpu().tolist())
         return pk, vk
 
     @staticmethod
@@ -720,7 +747,9 @@ class PlonkKzgSnark:
             buf[W].zero_()
             if pub_inputs[i]:
                 buf[W, :4 * len(pub_inputs[i])] = _dev_fr(mont(pub_inputs[i]))   # io gates sit in rows 0 .. num_inputs-1
-            L.ntt_device(c, buf.data_ptr(), log_n, W + 1, inverse=True, stream=st)
+            # an empty public input is the zero polynomial: nothing to transform in row W
+            L.ntt_device(c, buf.data_ptr(), log_n, W + (1 if pub_inputs[i] or not SKIP_ZERO_POLYS else 0), inverse=True,
+                         stream=st)
             wire_vals_v.append(wire_vals)
             bufs.append(buf)
         # the transcript is initialised (snark.rs:231-237) while the device runs the witness gather and the iNTTs
@@ -820,7 +849,10 @@ class PlonkKzgSnark:
                     L.poly_lincomb_device(c, [poly.data_ptr(), poly.data_ptr() + lc4 * 8], [k, k], fold,
                                           tmp[j].data_ptr(), k, stream=st)
                 cs[o_w:o_z + 1, :k * 4].copy_(tmp)
-            L.ntt_device(c, cs.data_ptr(), log_ml, npolys, inverse=False, coset_mont=off, in_len=lc4 // 4, stream=st)
+            zero_rows = [o_pi] if not pub_inputs[i] else []
+            if pk.coset_evals is None:
+                zero_rows += [j for j, z in enumerate(pk.selector_is_zero) if z]
+            _coset_ntt_rows(c, cs, zero_rows, log_ml, off, lc4 // 4, st)
             tick("r3_coset_ntts")
             chal = mont([alpha, beta, gamma, alpha_bases[i]])
             if G == 1:
@@ -1112,7 +1144,10 @@ class PlonkKzgSnark:
         cs[o_w:o_z, :l4].copy_(wire_polys)
         cs[o_z, :l4].copy_(perm_poly)
         cs[o_pi, :n4].copy_(pub_poly)
-        L.ntt_device(c, cs.data_ptr(), log_m, npolys, inverse=False, coset_mont=gen, in_len=ln, stream=st)
+        zero_rows = [o_pi] if not pub_input else []
+        if pk.coset_evals is None:
+            zero_rows += [j for j, z in enumerate(pk.selector_is_zero) if z]
+        _coset_ntt_rows(c, cs, zero_rows, log_m, gen, ln, st)
         quot = torch.zeros(m * 4, dtype=torch.int64, device="cuda")
         L.plonk_quotient_turbo_device(c, log_n, log_m, sel_ptr, sig_ptr, cs[o_w].data_ptr(), cs[o_z].data_ptr(),
                                       cs[o_pi].data_ptr(), mont(vk.k), mont([alpha, beta, gamma, alpha_base]),
