@@ -208,6 +208,19 @@ int32_t jfhip_plonk_quotient_coset_device(int32_t curve_id, uint32_t num_wire_ty
                                           const void *d_pub_input, const void *d_plookup, const uint64_t *k_mont,
                                           const uint64_t *challenges_mont, void *d_quot, jfhip_stream *stream);
 
+/* jfhip_plonk_quotient_coset_device for circuits that leave gate kinds unused (the reference evaluates every term at
+ * every point, prover.rs:665-699): bit j of zero_selector_mask set = selector polynomial j (the reference's order) is
+ * identically zero -- its row of d_selectors is never read, so it need not hold coset evaluations, and the products it
+ * would scale are not computed; d_pub_input may be NULL for an empty public input (pub_inp_poly = 0).  Same values in
+ * d_quot as the unmasked call on zero rows.  coset_offset_mont = Fr::GENERATOR and log_m = the full quotient domain give
+ * the reference's coset. */
+int32_t jfhip_plonk_quotient_masked_device(int32_t curve_id, uint32_t num_wire_types, uint32_t log_n, uint32_t log_m,
+                                           const uint64_t *coset_offset_mont, const void *d_selectors,
+                                           const void *d_sigmas, const void *d_wires, const void *d_prod_perm,
+                                           const void *d_pub_input, const void *d_plookup, const uint64_t *k_mont,
+                                           const uint64_t *challenges_mont, uint32_t zero_selector_mask, void *d_quot,
+                                           jfhip_stream *stream);
+
 /* ---- grand-product builders (next row) ------------------------------------ */
 
 /* Replaces the serial loop (one field division per row) of

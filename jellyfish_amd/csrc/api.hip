@@ -705,6 +705,36 @@ int32_t jfhip_plonk_quotient_coset_device(int32_t curve_id, uint32_t num_wire_ty
                                        k_mont, ch, (uint32_t*)d_quot, st);
 }
 
+int32_t jfhip_plonk_quotient_masked_device(int32_t curve_id, uint32_t num_wire_types, uint32_t log_n, uint32_t log_m,
+                                           const uint64_t* coset_offset_mont, const void* d_sel, const void* d_sig,
+                                           const void* d_wires, const void* d_zperm, const void* d_pi,
+                                           const void* d_plookup, const uint64_t* k_mont, const uint64_t* ch,
+                                           uint32_t zero_selector_mask, void* d_quot, jfhip_stream* stream) {
+    JF_TRY(check_curve(curve_id));
+    if (num_wire_types != 5 && num_wire_types != 6) {
+        set_error("quotient: %u wire types (5 = TurboPlonk, 6 = UltraPlonk)", num_wire_types);
+        return JFHIP_ERR_INVALID;
+    }
+    const uint32_t nsel = num_wire_types == 5 ? 13u : 14u;
+    if (zero_selector_mask >> nsel) {
+        set_error("quotient: zero_selector_mask 0x%x names selectors beyond the %u of this circuit type",
+                  zero_selector_mask, nsel);
+        return JFHIP_ERR_INVALID;
+    }
+    const bool all_zero = zero_selector_mask == ((1u << nsel) - 1u);
+    if (!coset_offset_mont || (!d_sel && !all_zero) || !d_sig || !d_wires || !d_zperm || !k_mont || !ch || !d_quot ||
+        (num_wire_types == 6 && !d_plookup)) {
+        set_error("null argument");
+        return JFHIP_ERR_INVALID;
+    }
+    JF_STREAM(st, stream);
+    std::lock_guard<std::mutex> lk(st->mu);
+    return plonk_quotient_coset_device(curve_id, (int)num_wire_types, log_n, log_m, coset_offset_mont,
+                                       (const uint32_t*)d_sel, (const uint32_t*)d_sig, (const uint32_t*)d_wires,
+                                       (const uint32_t*)d_zperm, (const uint32_t*)d_pi, (const uint32_t*)d_plookup,
+                                       k_mont, ch, (uint32_t*)d_quot, st, zero_selector_mask);
+}
+
 int32_t jfhip_plonk_perm_product_device(int32_t curve_id, uint32_t log_n, uint32_t num_wire_types,
                                         const void* d_wire_vals, const void* d_id_perm, const void* d_sigma_vals,
                                         const uint64_t* beta, const uint64_t* gamma, void* d_out,

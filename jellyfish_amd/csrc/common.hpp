@@ -117,7 +117,7 @@ int32_t plonk_quotient_coset_device(int32_t curve, int nw, uint32_t log_n, uint3
                                     const uint32_t* sel, const uint32_t* sig, const uint32_t* wires,
                                     const uint32_t* zperm, const uint32_t* pi, const uint32_t* lookup,
                                     const uint64_t* k_mont, const uint64_t* challenges_mont, uint32_t* out,
-                                    jfhip_stream* st);
+                                    jfhip_stream* st, uint32_t zero_selector_mask = 0);
 int32_t plonk_perm_product_device(int32_t curve, uint32_t log_n, uint32_t nw, const uint32_t* wires,
                                   const uint32_t* idp, const uint32_t* sig, const uint64_t* beta, const uint64_t* gamma,
                                   uint32_t* out, jfhip_stream* st);

@@ -157,7 +157,10 @@ __global__ __launch_bounds__(256) void k_quot(uint32_t log_n, uint32_t log_m, co
                                               const uint32_t* __restrict__ lk, const uint32_t* __restrict__ cst,
                                               const uint32_t* __restrict__ lo, const uint32_t* __restrict__ hi,
                                               uint32_t a, const uint32_t* __restrict__ inv_den,
-                                              const uint32_t* __restrict__ zh_inv, uint32_t* __restrict__ out) {
+                                              const uint32_t* __restrict__ zh_inv, uint32_t zmask,
+                                              uint32_t* __restrict__ out) {
+    // zmask bit j: selector polynomial j is identically zero (a gate kind the circuit never uses): its row is not read
+    // and the products it would scale are not computed (wave-uniform branches); pi == nullptr: empty public input
     constexpr int N = Fr::N;
     constexpr bool ULTRA = NW == 6;
     using F = Fp<Fr>;
@@ -175,20 +178,28 @@ __global__ __launch_bounds__(256) void k_quot(uint32_t log_n, uint32_t log_m, co
     for (int j = 0; j < NW; j++) w[j] = LD(wires, j);
 
     // ---- gate part (prover.rs:665-699); selector order q_lc[4] q_mul[2] q_hash[4] q_o q_c q_ecc
-    F acc = fp_add<Fr>(LD(sel, 11), fp_load<Fr>(pi + i * N));
+    auto live = [&](int j) { return ((zmask >> j) & 1u) == 0u; };
+    F acc = Fp<Fr>::zero();
+    if (live(11)) acc = LD(sel, 11);
+    if (pi) acc = fp_add<Fr>(acc, fp_load<Fr>(pi + i * N));
 #pragma unroll
-    for (int j = 0; j < 4; j++) acc = fp_add<Fr>(acc, fp_mul<Fr>(LD(sel, j), w[j]));
-    F w01 = fp_mul<Fr>(w[0], w[1]), w23 = fp_mul<Fr>(w[2], w[3]);
-    acc = fp_add<Fr>(acc, fp_mul<Fr>(LD(sel, 4), w01));
-    acc = fp_add<Fr>(acc, fp_mul<Fr>(LD(sel, 5), w23));
-    acc = fp_add<Fr>(acc, fp_mul<Fr>(LD(sel, 12), fp_mul<Fr>(fp_mul<Fr>(w01, w23), w[4])));
+    for (int j = 0; j < 4; j++)
+        if (live(j)) acc = fp_add<Fr>(acc, fp_mul<Fr>(LD(sel, j), w[j]));
+    if (live(4) || live(5) || live(12)) {
+        F w01 = fp_mul<Fr>(w[0], w[1]), w23 = fp_mul<Fr>(w[2], w[3]);
+        if (live(4)) acc = fp_add<Fr>(acc, fp_mul<Fr>(LD(sel, 4), w01));
+        if (live(5)) acc = fp_add<Fr>(acc, fp_mul<Fr>(LD(sel, 5), w23));
+        if (live(12)) acc = fp_add<Fr>(acc, fp_mul<Fr>(LD(sel, 12), fp_mul<Fr>(fp_mul<Fr>(w01, w23), w[4])));
+    }
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        F w2 = fp_sqr<Fr>(w[j]);
-        F w5 = fp_mul<Fr>(fp_sqr<Fr>(w2), w[j]);
-        acc = fp_add<Fr>(acc, fp_mul<Fr>(LD(sel, 6 + j), w5));
+        if (live(6 + j)) {
+            F w2 = fp_sqr<Fr>(w[j]);
+            F w5 = fp_mul<Fr>(fp_sqr<Fr>(w2), w[j]);
+            acc = fp_add<Fr>(acc, fp_mul<Fr>(LD(sel, 6 + j), w5));
+        }
     }
-    acc = fp_sub<Fr>(acc, fp_mul<Fr>(LD(sel, 10), w[4]));
+    if (live(10)) acc = fp_sub<Fr>(acc, fp_mul<Fr>(LD(sel, 10), w[4]));
 
     // ---- copy-constraint part (prover.rs:709-752)
     const F x = fp_mul<Fr>(CS(QC_GEN), root_pow<Fr>(lo, hi, a, i));  // eval_point = g * w^i
@@ -210,7 +221,7 @@ __global__ __launch_bounds__(256) void k_quot(uint32_t log_n, uint32_t log_m, co
         // ---- Plookup part (prover.rs:766-882)
         const F tau = CS(QC_TAU);
         const F lnd = fp_load<Fr>(inv_den + nx * N);
-        const F ql = LD(sel, 13), qlw = LDN(sel, 13);
+        const F ql = live(13) ? LD(sel, 13) : Fp<Fr>::zero(), qlw = live(13) ? LDN(sel, 13) : Fp<Fr>::zero();
         const F h1x = LD(lk, 4), h1w = LDN(lk, 4), h2x = LD(lk, 5), h2w = LDN(lk, 5), px = LD(lk, 6), pw = LDN(lk, 6);
         // eval_merged_table at x and x*w, eval_merged_lookup_witness at x (structs.rs:899-931)
         F t = fp_add<Fr>(fp_mul<Fr>(tau, w[4]), w[3]);
@@ -250,7 +261,7 @@ template <class Fr>
 static int32_t quotient_t(int32_t curve, int nw, uint32_t log_n, uint32_t log_m, const uint32_t* sel,
                           const uint32_t* sig, const uint32_t* wires, const uint32_t* zperm, const uint32_t* pi,
                           const uint32_t* lookup, const uint64_t* k_mont, const uint64_t* ch, uint32_t* out,
-                          jfhip_stream* st, const uint64_t* offset_mont = nullptr) {
+                          jfhip_stream* st, const uint64_t* offset_mont = nullptr, uint32_t zmask = 0) {
     constexpr int N = Fr::N;
     CosetOffset gen;
     memset(&gen, 0, sizeof(gen));
@@ -312,10 +323,10 @@ static int32_t quotient_t(int32_t curve, int nw, uint32_t log_n, uint32_t log_m,
     const dim3 grid((unsigned)((m + 255) / 256));
     if (nw == 5)
         hipLaunchKernelGGL((k_quot<Fr, 5>), grid, dim3(256), 0, st->s, log_n, log_m, sel, sig, wires, zperm, pi,
-                           (const uint32_t*)nullptr, d_cst, lo, hi, a, qd.inv_den, qd.zh_inv, out);
+                           (const uint32_t*)nullptr, d_cst, lo, hi, a, qd.inv_den, qd.zh_inv, zmask, out);
     else
         hipLaunchKernelGGL((k_quot<Fr, 6>), grid, dim3(256), 0, st->s, log_n, log_m, sel, sig, wires, zperm, pi, lookup,
-                           d_cst, lo, hi, a, qd.inv_den, qd.zh_inv, out);
+                           d_cst, lo, hi, a, qd.inv_den, qd.zh_inv, zmask, out);
     JF_HIP(hipGetLastError());
     return JFHIP_OK;
 }
@@ -335,12 +346,12 @@ int32_t plonk_quotient_coset_device(int32_t curve, int nw, uint32_t log_n, uint3
                                     const uint32_t* sel, const uint32_t* sig, const uint32_t* wires,
                                     const uint32_t* zperm, const uint32_t* pi, const uint32_t* lookup,
                                     const uint64_t* k_mont, const uint64_t* challenges_mont, uint32_t* out,
-                                    jfhip_stream* st) {
+                                    jfhip_stream* st, uint32_t zmask) {
     if (curve == JFHIP_BN254)
         return quotient_t<Bn254Fr>(curve, nw, log_n, log_m, sel, sig, wires, zperm, pi, lookup, k_mont, challenges_mont,
-                                   out, st, offset_mont);
+                                   out, st, offset_mont, zmask);
     return quotient_t<Bls381Fr>(curve, nw, log_n, log_m, sel, sig, wires, zperm, pi, lookup, k_mont, challenges_mont, out,
-                                st, offset_mont);
+                                st, offset_mont, zmask);
 }
 
 int32_t plonk_quotient_ultra_device(int32_t curve, uint32_t log_n, uint32_t log_m, const uint32_t* sel,

@@ -35,7 +35,7 @@ SYMBOLS = [
     "jfhip_stream_sync", "jfhip_stream_raw", "jfhip_stream_wrap", "jfhip_srs_load", "jfhip_srs_load_device",
     "jfhip_srs_gen_for_testing", "jfhip_srs_free", "jfhip_srs_len", "jfhip_srs_window_bits", "jfhip_srs_read",
     "jfhip_msm", "jfhip_msm_batch", "jfhip_msm_batch_device", "jfhip_msm_device", "jfhip_msm_partial_device", "jfhip_g1_sum_partials",
-    "jfhip_kzg_open", "jfhip_ntt", "jfhip_ntt_device", "jfhip_plonk_quotient_turbo_device", "jfhip_plonk_quotient_ultra_device", "jfhip_plonk_quotient_coset_device", "jfhip_plonk_perm_product_device", "jfhip_plonk_lookup_product_device", "jfhip_poly_divide_linear_device",
+    "jfhip_kzg_open", "jfhip_ntt", "jfhip_ntt_device", "jfhip_plonk_quotient_turbo_device", "jfhip_plonk_quotient_ultra_device", "jfhip_plonk_quotient_coset_device", "jfhip_plonk_quotient_masked_device", "jfhip_plonk_perm_product_device", "jfhip_plonk_lookup_product_device", "jfhip_poly_divide_linear_device",
     "jfhip_poly_lincomb_device", "jfhip_poly_eval_batch_device", "jfhip_field_op", "jfhip_g1_op", "jfhip_probe",
     "jfhip_set_profiling", "jfhip_last_phase_ms", "jfhip_phase_name", "jfhip_keccak_f1600",
 ]
@@ -303,6 +303,22 @@ def plonk_quotient_coset_device(curve: int, num_wire_types: int, log_n: int, log
                                                             _vp(d_prod_perm), _vp(d_pub_input),
                                                             _vp(d_plookup) if d_plookup else None, _p(k), _p(ch),
                                                             _vp(d_quot), _sh(stream)))
+
+
+def plonk_quotient_masked_device(curve: int, num_wire_types: int, log_n: int, log_m: int, coset_offset_mont,
+                                 d_selectors: int, d_sigmas: int, d_wires: int, d_prod_perm: int, d_pub_input: int,
+                                 d_plookup: int, k_mont, challenges_mont, zero_selector_mask: int, d_quot: int,
+                                 stream: Stream | None = None):
+    """plonk_quotient_coset_device that skips identically-zero selectors (mask bit j) and a NULL public input"""
+    off, k, ch = _u64(coset_offset_mont), _u64(k_mont), _u64(challenges_mont)
+    assert off.size == 4 and k.size == 4 * num_wire_types and ch.size == 4 * (num_wire_types - 1)
+    _check(load_library().jfhip_plonk_quotient_masked_device(curve, num_wire_types, log_n, log_m, _p(off),
+                                                             _vp(d_selectors) if d_selectors else None, _vp(d_sigmas),
+                                                             _vp(d_wires), _vp(d_prod_perm),
+                                                             _vp(d_pub_input) if d_pub_input else None,
+                                                             _vp(d_plookup) if d_plookup else None, _p(k), _p(ch),
+                                                             ctypes.c_uint32(zero_selector_mask), _vp(d_quot),
+                                                             _sh(stream)))
 
 
 def plonk_perm_product_device(curve: int, log_n: int, num_wire_types: int, d_wire_vals: int, d_id_perm: int,

@@ -554,15 +554,14 @@ SKIP_ZERO_POLYS = True   # False: transform every polynomial like the reference 
 
 def _coset_ntt_rows(c: int, cs: torch.Tensor, zero_rows, log_len: int, off, in_len: int, st):
     """forward coset NTT of the rows of `cs` (one polynomial per row, first in_len coefficients set), except the rows in
-    zero_rows, which hold the zero polynomial: those are filled with zeros.  The reference transforms all of them
-    (prover.rs:534-549); an identically-zero selector (a gate kind the circuit never uses) or an empty public input has
-    zero evaluations anyway."""
+    zero_rows, which stand for the zero polynomial: those are left alone (the masked quotient call never reads them).
+    The reference transforms all of them (prover.rs:534-549); an identically-zero selector (a gate kind the circuit
+    never uses) or an empty public input has zero evaluations anyway."""
     rows = cs.shape[0]
-    zero_rows = set(zero_rows) if SKIP_ZERO_POLYS else set()
+    zero_rows = set(zero_rows)
     j = 0
     while j < rows:
         if j in zero_rows:
-            cs[j].zero_()
             j += 1
             continue
         k = j
@@ -849,20 +848,19 @@ class PlonkKzgSnark:
                     L.poly_lincomb_device(c, [poly.data_ptr(), poly.data_ptr() + lc4 * 8], [k, k], fold,
                                           tmp[j].data_ptr(), k, stream=st)
                 cs[o_w:o_z + 1, :k * 4].copy_(tmp)
-            zero_rows = [o_pi] if not pub_inputs[i] else []
+            # identically-zero polynomials: no transform, and the quotient kernel is told not to read their rows
+            zmask = sum(1 << j for j, z in enumerate(pk.selector_is_zero) if z) if SKIP_ZERO_POLYS else 0
+            pi_zero = SKIP_ZERO_POLYS and not pub_inputs[i]
+            zero_rows = [o_pi] if pi_zero else []
             if pk.coset_evals is None:
-                zero_rows += [j for j, z in enumerate(pk.selector_is_zero) if z]
+                zero_rows += [j for j in range(NSEL) if (zmask >> j) & 1]
             _coset_ntt_rows(c, cs, zero_rows, log_ml, off, lc4 // 4, st)
             tick("r3_coset_ntts")
             chal = mont([alpha, beta, gamma, alpha_bases[i]])
-            if G == 1:
-                L.plonk_quotient_turbo_device(c, log_n, log_m, sel_ptr, sig_ptr, cs[o_w].data_ptr(),
-                                              cs[o_z].data_ptr(), cs[o_pi].data_ptr(), mont(vk.k), chal,
-                                              quot.data_ptr(), stream=st)
-            else:
-                L.plonk_quotient_coset_device(c, W, log_n, log_ml, off, sel_ptr, sig_ptr, cs[o_w].data_ptr(),
-                                              cs[o_z].data_ptr(), cs[o_pi].data_ptr(), 0, mont(vk.k), chal,
-                                              part.data_ptr(), stream=st)
+            # G == 1: the slice is the whole quotient coset (offset Fr::GENERATOR, log_ml = log_m)
+            L.plonk_quotient_masked_device(c, W, log_n, log_ml, off, sel_ptr, sig_ptr, cs[o_w].data_ptr(),
+                                           cs[o_z].data_ptr(), 0 if pi_zero else cs[o_pi].data_ptr(), 0, mont(vk.k), chal,
+                                           zmask, (quot if G == 1 else part).data_ptr(), stream=st)
             del cs                             # stream-ordered: the next allocation is used on the same stream
             tick("r3_quotient_intt")
         if G == 1:
@@ -1144,14 +1142,16 @@ class PlonkKzgSnark:
         cs[o_w:o_z, :l4].copy_(wire_polys)
         cs[o_z, :l4].copy_(perm_poly)
         cs[o_pi, :n4].copy_(pub_poly)
-        zero_rows = [o_pi] if not pub_input else []
+        zmask = sum(1 << j for j, z in enumerate(pk.selector_is_zero) if z) if SKIP_ZERO_POLYS else 0
+        pi_zero = SKIP_ZERO_POLYS and not pub_input
+        zero_rows = [o_pi] if pi_zero else []
         if pk.coset_evals is None:
-            zero_rows += [j for j, z in enumerate(pk.selector_is_zero) if z]
+            zero_rows += [j for j in range(NSEL) if (zmask >> j) & 1]
         _coset_ntt_rows(c, cs, zero_rows, log_m, gen, ln, st)
         quot = torch.zeros(m * 4, dtype=torch.int64, device="cuda")
-        L.plonk_quotient_turbo_device(c, log_n, log_m, sel_ptr, sig_ptr, cs[o_w].data_ptr(), cs[o_z].data_ptr(),
-                                      cs[o_pi].data_ptr(), mont(vk.k), mont([alpha, beta, gamma, alpha_base]),
-                                      quot.data_ptr(), stream=st)
+        L.plonk_quotient_masked_device(c, W, log_n, log_m, gen, sel_ptr, sig_ptr, cs[o_w].data_ptr(), cs[o_z].data_ptr(),
+                                       0 if pi_zero else cs[o_pi].data_ptr(), 0, mont(vk.k),
+                                       mont([alpha, beta, gamma, alpha_base]), zmask, quot.data_ptr(), stream=st)
         del cs
         L.ntt_device(c, quot.data_ptr(), log_m, 1, inverse=True, coset_mont=gen, stream=st)
         expected_degree = W * (n + 1) + 2
