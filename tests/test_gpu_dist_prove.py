@@ -198,6 +198,10 @@ def _real_batch_worker(rank, world, port, q):
         srs = JP.PlonkKzgSnark.universal_setup_for_testing(0, css[0].eval_domain_size() + 2, BETA)
         keys = [JP.PlonkKzgSnark.preprocess(srs, c) for c in css]
         ref = JP.PlonkKzgSnark.batch_prove(JP.H.test_rng(), css, [k[0] for k in keys], b"cfg5").serialize_compressed()
+        # the other multi-GPU layout of the same call: every rank holds every circuit, commitments' point ranges and the
+        # quotient coset are split over the ranks (batch_prove(sharded=True))
+        shard = JP.PlonkKzgSnark.batch_prove(JP.H.test_rng(), css, [k[0] for k in keys], b"cfg5", sharded=True)
+        assert shard.serialize_compressed() == ref, "sharded batch_prove differs"
         got = JP.PlonkKzgSnark.batch_prove_one_per_rank(JP.H.test_rng(), css[rank], keys[rank][0], b"cfg5")
         keys[rank][0].keep_coset_evals()
         kept = JP.PlonkKzgSnark.batch_prove_one_per_rank(JP.H.test_rng(), css[rank], keys[rank][0], b"cfg5")
