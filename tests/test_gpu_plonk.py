@@ -93,11 +93,12 @@ def test_prove_rejects_unsatisfied_and_mismatched(hip):
         JP.PlonkKzgSnark.preprocess(small, cs)
 
 
-@pytest.mark.parametrize("log_gates", [16, 20])
+@pytest.mark.parametrize("log_gates", [16, 20, 22])
 def test_bench_circuit_proof_verifies(hip, log_gates):
-    """gen_circuit_for_bench shape (plonk/benches/bench.rs:29-46: a chain of additions), 2^16 and BASELINE config 4's
-    2^20 gates, BN254: the proof computed on the device verifies under the restated verifier (size-independent
-    property; the oracle prover would take hours at this size, its verifier is O(1))."""
+    """gen_circuit_for_bench shape (plonk/benches/bench.rs:29-46: a chain of additions), 2^16, BASELINE config 4's 2^20
+    and 2^22 gates (quotient domain 2^25, 32 GiB of HBM), BN254: the proof computed on the device verifies under the
+    restated verifier (size-independent property; the oracle prover would take hours at this size, its verifier is
+    O(1)).  scripts/prove_big.py runs the same check at 2^24 gates (128 GiB, 0.71 s per proof)."""
     from jellyfish_amd import plonk as JP
 
     cv = R.BN254
@@ -116,6 +117,8 @@ def test_bench_circuit_proof_verifies(hip, log_gates):
     # the bench circuit uses 4 of the 13 selectors and has no public input: prove() fills the coset evaluations of the
     # identically-zero polynomials instead of transforming them; transforming all 25 like the reference gives the same bytes
     assert sum(pk.selector_is_zero) == 9
+    if log_gates > 20:
+        return
     JP.SKIP_ZERO_POLYS = False
     try:
         assert JP.PlonkKzgSnark.prove(JP.H.test_rng(), cs, pk).serialize_compressed() == proof.serialize_compressed()
