@@ -1,4 +1,4 @@
-"""Developer check: PlonkKzgSnark::prove at 2^K gates (BN254 bench circuit) verifies under the restated verifier; timing."""
+"""Manual GPU check (not collected by pytest; run as `python tests/manual_prove_big.py 24`): PlonkKzgSnark::prove at 2^K gates (BN254 bench circuit) verifies under the restated verifier; timing."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -98,7 +98,7 @@ def test_bench_circuit_proof_verifies(hip, log_gates):
     """gen_circuit_for_bench shape (plonk/benches/bench.rs:29-46: a chain of additions), 2^16, BASELINE config 4's 2^20
     and 2^22 gates (quotient domain 2^25, 32 GiB of HBM), BN254: the proof computed on the device verifies under the
     restated verifier (size-independent property; the oracle prover would take hours at this size, its verifier is
-    O(1)).  scripts/prove_big.py runs the same check at 2^24 gates (128 GiB, 0.71 s per proof)."""
+    O(1)).  tests/manual_prove_big.py runs the same check at 2^24 gates (128 GiB, 0.71 s per proof)."""
     from jellyfish_amd import plonk as JP
 
     cv = R.BN254
