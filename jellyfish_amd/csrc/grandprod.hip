@@ -159,6 +159,49 @@ static int32_t prefix_product_t(uint32_t* d_io, size_t m, jfhip_stream* st) {
     return JFHIP_OK;
 }
 
+// ---- permutation product without per-chunk inversions ---------------------------------------------
+// z[j+1] = prod_{k<=j} a_k / prod_{k<=j} b_k.  With PA = prefix products of the numerators and PR = prefix products of
+// the REVERSED denominators, 1 / prod_{k<=j} b_k = (prod_{k>j} b_k) / D = PR[n-3-j] / D, D = PR[n-2] the product of all
+// denominators: two scans, ONE inversion, two products per row.  (k_gp_perm_ratio inverts once per 8 rows: 24 field
+// elements live per lane, 2 waves per SIMD, a divergent binary-Euclid loop -- 1.17 ms at n = 2^20; this path 0.4 ms.)
+template <class Fr>
+__global__ __launch_bounds__(256) void k_gp_perm_terms(uint32_t n, uint32_t nw, const uint32_t* __restrict__ wires,
+                                                       const uint32_t* __restrict__ idp,
+                                                       const uint32_t* __restrict__ sig,
+                                                       const uint32_t* __restrict__ cst, uint32_t* __restrict__ num,
+                                                       uint32_t* __restrict__ den_rev) {
+    constexpr int N = Fr::N;
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j + 1 >= n) return;
+    const Fp<Fr> beta = fp_load<Fr>(cst), gamma = fp_load<Fr>(cst + N);
+    Fp<Fr> a = Fp<Fr>::one(), b = Fp<Fr>::one();
+    for (uint32_t i = 0; i < nw; i++) {
+        const size_t e = ((size_t)i * n + j) * N;
+        Fp<Fr> t = fp_add<Fr>(fp_load<Fr>(wires + e), gamma);
+        a = fp_mul<Fr>(a, fp_add<Fr>(t, fp_mul<Fr>(beta, fp_load<Fr>(idp + e))));
+        b = fp_mul<Fr>(b, fp_add<Fr>(t, fp_mul<Fr>(beta, fp_load<Fr>(sig + e))));
+    }
+    fp_store<Fr>(num + (size_t)j * N, a);
+    fp_store<Fr>(den_rev + (size_t)(n - 2 - j) * N, b);
+}
+template <class Fr>
+__global__ void k_gp_inv_one(const uint32_t* __restrict__ in, uint32_t* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) fp_store<Fr>(out, fp_inv_binary<Fr>(fp_load<Fr>(in)));
+}
+template <class Fr>
+__global__ __launch_bounds__(256) void k_gp_perm_combine(uint32_t n, const uint32_t* __restrict__ pa,
+                                                         const uint32_t* __restrict__ pr,
+                                                         const uint32_t* __restrict__ inv_total,
+                                                         uint32_t* __restrict__ x) {
+    constexpr int N = Fr::N;
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j == 0) fp_store<Fr>(x, Fp<Fr>::one());
+    if (j + 1 >= n) return;
+    Fp<Fr> r = fp_mul<Fr>(fp_load<Fr>(pa + (size_t)j * N), fp_load<Fr>(inv_total));
+    if (j + 2 < n) r = fp_mul<Fr>(r, fp_load<Fr>(pr + (size_t)(n - 3 - j) * N));
+    fp_store<Fr>(x + (size_t)(j + 1) * N, r);
+}
+
 template <class Fr>
 static int32_t upload_beta_gamma(const uint64_t* beta, const uint64_t* gamma, uint32_t** d_cst, jfhip_stream* st) {
     JF_TRY(st->poly_c.ensure(2 * Fr::N * 4));
@@ -175,13 +218,32 @@ static int32_t perm_product_t(uint32_t log_n, uint32_t nw, const uint32_t* wires
                               const uint32_t* sig, const uint64_t* beta, const uint64_t* gamma, uint32_t* out,
                               jfhip_stream* st) {
     const size_t n = (size_t)1 << log_n;
+    constexpr int N = Fr::N;
     uint32_t* d_cst;
     JF_TRY(upload_beta_gamma<Fr>(beta, gamma, &d_cst, st));
-    const size_t lanes = (n + GP_INV_CHUNK - 1) / GP_INV_CHUNK;
-    hipLaunchKernelGGL((k_gp_perm_ratio<Fr>), dim3((unsigned)((lanes + 127) / 128)), dim3(128), 0, st->s, (uint32_t)n,
-                       nw, wires, idp, sig, d_cst, out);
+    static const bool per_chunk = getenv("JFHIP_GP_PER_CHUNK_INVERSION") != nullptr;   // the first formulation, kept for A/B runs
+    if (per_chunk || n < 4) {
+        const size_t lanes = (n + GP_INV_CHUNK - 1) / GP_INV_CHUNK;
+        hipLaunchKernelGGL((k_gp_perm_ratio<Fr>), dim3((unsigned)((lanes + 127) / 128)), dim3(128), 0, st->s,
+                           (uint32_t)n, nw, wires, idp, sig, d_cst, out);
+        JF_HIP(hipGetLastError());
+        return prefix_product_t<Fr>(out, n, st);
+    }
+    // numerators, reversed denominators (n - 1 each) and the inverse of the total, in the stream's scratch
+    JF_TRY(st->poly_a.ensure((2 * n + 1) * N * 4));
+    uint32_t* num = st->poly_a.as<uint32_t>();
+    uint32_t* den_rev = num + n * N;
+    uint32_t* inv_total = num + 2 * n * N;
+    const dim3 grid((unsigned)((n + 255) / 256));
+    hipLaunchKernelGGL((k_gp_perm_terms<Fr>), grid, dim3(256), 0, st->s, (uint32_t)n, nw, wires, idp, sig, d_cst, num,
+                       den_rev);
     JF_HIP(hipGetLastError());
-    return prefix_product_t<Fr>(out, n, st);
+    JF_TRY(prefix_product_t<Fr>(num, n - 1, st));
+    JF_TRY(prefix_product_t<Fr>(den_rev, n - 1, st));
+    hipLaunchKernelGGL((k_gp_inv_one<Fr>), dim3(1), dim3(64), 0, st->s, den_rev + (n - 2) * N, inv_total);
+    hipLaunchKernelGGL((k_gp_perm_combine<Fr>), grid, dim3(256), 0, st->s, (uint32_t)n, num, den_rev, inv_total, out);
+    JF_HIP(hipGetLastError());
+    return JFHIP_OK;
 }
 
 template <class Fr>
