@@ -266,6 +266,15 @@ int32_t jfhip_poly_eval_batch_device(int32_t curve_id, const void *const *d_poly
 int32_t jfhip_poly_lincomb_device(int32_t curve_id, const void *const *d_polys, const size_t *lens, size_t count,
                                   const uint64_t *coeffs_mont, void *d_out, size_t n, jfhip_stream *stream);
 
+/* Replaces the witness gather of Arithmetization::compute_wire_polynomials
+ * (relation/src/constraint_system.rs:1422-1444: `self.witness[var]` for every (wire type, gate) before the ifft) on DEVICE
+ * data: d_out[i] = d_witness[d_wire_variables[i]], i < count, rows of 32 bytes (one Fr, Montgomery limbs as everywhere);
+ * d_witness has num_vars rows (< 2^32), d_wire_variables is a DEVICE array of uint32 (wire type major: index
+ * wire_type * n + gate, the layout jfhip_ntt_device takes as a batch).  check != 0: synchronises and returns
+ * JFHIP_ERR_INVALID if any index was >= num_vars (such rows read variable 0); check == 0: asynchronous on `stream`. */
+int32_t jfhip_witness_gather_device(const void *d_witness, size_t num_vars, const uint32_t *d_wire_variables,
+                                    size_t count, void *d_out, int32_t check, jfhip_stream *stream);
+
 /* ---- field / group vector ops (test and glue surface) -------------------------------------- */
 
 /* field_id: 0 BN254 Fr, 1 BN254 Fq, 2 BLS12-381 Fr, 3 BLS12-381 Fq.

@@ -809,6 +809,28 @@ int32_t jfhip_poly_lincomb_device(int32_t curve_id, const void* const* d_polys, 
     return poly_lincomb_device(curve_id, (const uint32_t* const*)d_polys, lens, count, coeffs, (uint32_t*)d_out, n, st);
 }
 
+int32_t jfhip_witness_gather_device(const void* d_witness, size_t num_vars, const uint32_t* d_wire_variables,
+                                    size_t count, void* d_out, int32_t check, jfhip_stream* stream) {
+    if (count == 0) return JFHIP_OK;
+    if (!d_witness || !d_wire_variables || !d_out || num_vars == 0 || num_vars >= ((size_t)1 << 32)) {
+        set_error("witness gather: null argument or bad table size %zu", num_vars);
+        return JFHIP_ERR_INVALID;
+    }
+    JF_STREAM(st, stream);
+    std::lock_guard<std::mutex> lk(st->mu);
+    JF_TRY(witness_gather_device((const uint32_t*)d_witness, num_vars, d_wire_variables, count, (uint32_t*)d_out, st));
+    if (check) {
+        uint32_t bad = 0;
+        JF_HIP(hipMemcpyAsync(&bad, st->poly_c.as<uint32_t>() + 24, 4, hipMemcpyDeviceToHost, st->s));
+        JF_HIP(hipStreamSynchronize(st->s));
+        if (bad) {
+            set_error("witness gather: a wire variable index is >= num_vars (%zu)", num_vars);
+            return JFHIP_ERR_INVALID;
+        }
+    }
+    return JFHIP_OK;
+}
+
 // ---- field / group test surface ---------------------------------------------------------------------
 
 int32_t jfhip_field_op(int32_t field_id, int32_t op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {

@@ -470,4 +470,34 @@ int32_t probe(int32_t kind, int32_t arg, double* out) {
     return JFHIP_OK;
 }
 
+// ---- witness gather (Arithmetization::compute_wire_polynomials, relation/src/constraint_system.rs:1422-1444, before its
+// ifft): out[i] = witness[wire_variables[i]], 32-byte rows.  One lane per row, two 16-byte loads and stores; the table
+// (num_vars x 32 B) is read at random and mostly stays in L2 / Infinity Cache, the output is written once, coalesced.
+__global__ __launch_bounds__(256) void k_gather_rows32(const uint4* __restrict__ table, uint32_t rows,
+                                                       const uint32_t* __restrict__ idx, size_t count,
+                                                       uint4* __restrict__ out, uint32_t* __restrict__ bad) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    uint32_t v = idx[i];
+    if (v >= rows) {  // reported to the host instead of faulting
+        *bad = 1u;
+        v = 0;
+    }
+    const uint4 a = table[2 * (size_t)v], b = table[2 * (size_t)v + 1];
+    out[2 * i] = a;
+    out[2 * i + 1] = b;
+}
+
+int32_t witness_gather_device(const uint32_t* d_witness, size_t num_vars, const uint32_t* d_wire_variables, size_t count,
+                              uint32_t* d_out, jfhip_stream* st) {
+    if (count == 0) return JFHIP_OK;
+    JF_TRY(st->poly_c.ensure(128));
+    uint32_t* bad = st->poly_c.as<uint32_t>() + 24;  // past the 64 bytes of constants other calls keep at the front
+    JF_HIP(hipMemsetAsync(bad, 0, 4, st->s));
+    hipLaunchKernelGGL(k_gather_rows32, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st->s,
+                       (const uint4*)d_witness, (uint32_t)num_vars, d_wire_variables, count, (uint4*)d_out, bad);
+    JF_HIP(hipGetLastError());
+    return JFHIP_OK;
+}
+
 }  // namespace jf

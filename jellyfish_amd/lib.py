@@ -35,7 +35,7 @@ SYMBOLS = [
     "jfhip_stream_sync", "jfhip_stream_raw", "jfhip_stream_wrap", "jfhip_srs_load", "jfhip_srs_load_device",
     "jfhip_srs_gen_for_testing", "jfhip_srs_free", "jfhip_srs_len", "jfhip_srs_window_bits", "jfhip_srs_read",
     "jfhip_msm", "jfhip_msm_batch", "jfhip_msm_batch_device", "jfhip_msm_device", "jfhip_msm_partial_device", "jfhip_g1_sum_partials",
-    "jfhip_kzg_open", "jfhip_ntt", "jfhip_ntt_device", "jfhip_plonk_quotient_turbo_device", "jfhip_plonk_quotient_ultra_device", "jfhip_plonk_quotient_coset_device", "jfhip_plonk_quotient_masked_device", "jfhip_plonk_perm_product_device", "jfhip_plonk_lookup_product_device", "jfhip_poly_divide_linear_device",
+    "jfhip_kzg_open", "jfhip_ntt", "jfhip_ntt_device", "jfhip_plonk_quotient_turbo_device", "jfhip_plonk_quotient_ultra_device", "jfhip_plonk_quotient_coset_device", "jfhip_plonk_quotient_masked_device", "jfhip_plonk_perm_product_device", "jfhip_plonk_lookup_product_device", "jfhip_witness_gather_device", "jfhip_poly_divide_linear_device",
     "jfhip_poly_lincomb_device", "jfhip_poly_eval_batch_device", "jfhip_field_op", "jfhip_g1_op", "jfhip_probe",
     "jfhip_set_profiling", "jfhip_last_phase_ms", "jfhip_phase_name", "jfhip_keccak_f1600",
 ]
@@ -352,6 +352,13 @@ def poly_eval_batch_device(curve: int, d_polys, lens, point_mont, d_out: int, st
     z = _u64(point_mont)
     _check(load_library().jfhip_poly_eval_batch_device(curve, ptrs, ls, ctypes.c_size_t(count), _p(z), _vp(d_out),
                                                        _sh(stream)))
+
+
+def witness_gather_device(d_witness: int, num_vars: int, d_wire_variables: int, count: int, d_out: int,
+                          check: bool = False, stream: Stream | None = None):
+    """d_out[i] = d_witness[d_wire_variables[i]] (32-byte rows; uint32 indices on the device)"""
+    _check(load_library().jfhip_witness_gather_device(_vp(d_witness), ctypes.c_size_t(num_vars), _vp(d_wire_variables),
+                                                      ctypes.c_size_t(count), _vp(d_out), int(bool(check)), _sh(stream)))
 
 
 def poly_lincomb_device(curve: int, d_polys, lens, coeffs_mont, d_out: int, n: int, stream: Stream | None = None):

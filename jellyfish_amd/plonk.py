@@ -283,6 +283,13 @@ class ProvingKey:
     id_perm_vals: torch.Tensor = field(repr=False, default=None)
     sigma_vals: torch.Tensor = field(repr=False, default=None)
     wire_variables: torch.Tensor = field(repr=False, default=None)
+
+    @property
+    def wire_variables32(self) -> torch.Tensor:
+        """the wire -> variable table as the uint32 indices jfhip_witness_gather_device takes (built once)"""
+        if getattr(self, "_wv32", None) is None:
+            self._wv32 = self.wire_variables.to(torch.int32).contiguous()
+        return self._wv32
     # optional: the 13 selector + W sigma polynomials evaluated on the quotient coset (m = 8n points each), kept in HBM.
     # The reference recomputes these 18 coset FFTs in every proof (prover.rs:534-544); they depend on the proving key
     # only, and 288 GB of HBM holds them (18 x 256 MiB at n = 2^20).  Same values, so the same proof bytes.
@@ -740,7 +747,12 @@ class PlonkKzgSnark:
         for i, (circuit, pk) in enumerate(zip(circuits, prove_keys)):
             wm = witness_monts[i] if witness_monts is not None and witness_monts[i] is not None else mont(circuit.witness)
             wit = _dev_fr(wm).view(-1, 4)
-            wire_vals = wit[pk.wire_variables].view(W, n4)
+            if wit.shape[0] != circuit.num_vars():
+                raise PlonkError("witness table has %d rows, the circuit %d variables" % (wit.shape[0], circuit.num_vars()))
+            # witness[wire_variable(i, j)] for every (wire type, gate) (constraint_system.rs:1422-1444): one gather kernel
+            wire_vals = torch.empty(W, n4, dtype=torch.int64, device="cuda")
+            L.witness_gather_device(wit.data_ptr(), wit.shape[0], pk.wire_variables32.data_ptr(), W * n,
+                                    wire_vals.data_ptr(), stream=st)
             buf = torch.empty(W + 1, n4, dtype=torch.int64, device="cuda")
             buf[:W].copy_(wire_vals)
             buf[W].zero_()
@@ -1088,7 +1100,11 @@ class PlonkKzgSnark:
         # ---- Round 1: the RNG draws of all instances in order, this rank keeps its own
         bs = [[[H.fr_rand(cp, rng) for _ in range(2)] for _ in range(W)] for _ in range(G)][me]
         wit = _dev_fr(witness_mont if witness_mont is not None else mont(circuit.witness)).view(-1, 4)
-        wire_vals = wit[pk.wire_variables].view(W, n4)
+        if wit.shape[0] != circuit.num_vars():
+            raise PlonkError("witness table has %d rows, the circuit %d variables" % (wit.shape[0], circuit.num_vars()))
+        wire_vals = torch.empty(W, n4, dtype=torch.int64, device="cuda")
+        L.witness_gather_device(wit.data_ptr(), wit.shape[0], pk.wire_variables32.data_ptr(), W * n, wire_vals.data_ptr(),
+                                stream=st)
         buf = torch.empty(W + 1, n4, dtype=torch.int64, device="cuda")
         buf[:W].copy_(wire_vals)
         buf[W].zero_()
