@@ -504,12 +504,17 @@ def main():
                                                      "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}}
             L.set_profiling(False)
             try:   # HBM bytes per transform from the rocprofv3 --pmc passes (profiles/pmc_latest.json), if collected
+                # the transforms read with 16-byte-per-lane streaming loads, for which gfx950's FETCH_SIZE counts half the
+                # bytes (MI355X_MICROARCH.md, HBM section): the corrected figure is 2 x FETCH_SIZE + WRITE_SIZE
                 ntt_traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json"))).get(
-                    "ntt_8x2^22_bls_hbm_bytes_per_transform")
+                    "ntt_8x2^22_bls_hbm_bytes_per_transform_upper")
             except Exception:
                 ntt_traffic = None
             for k in res_ntt:
                 res_ntt[k]["roofline"]["traffic"] = ntt_traffic
+                res_ntt[k]["roofline"]["traffic_note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, "
+                                                          "scripts/pmc_collect.sh), per transform = 3 digit passes: "
+                                                          "3.3 x the algorithmic 2.147e9 B")
             out["ntt"] = {"workload": "8 x 2^22 BLS12-381 Fr coset NTT (h = 7), device resident",
                           "algorithmic_bytes": "64 B per element per transform", **res_ntt}
 
