@@ -927,7 +927,8 @@ int windows_for(int32_t curve, int c) {
 }
 
 int choose_window_bits(int32_t curve, size_t n) {
-    // minimise n * W(c) * 10 + 2^(c-1) * 60 field multiplications (accumulate + fold)
+    // minimise n * W(c) * 10 + 2^(c-1) * 60 field multiplications (accumulate + fold): reproduces the measured optimum
+    // for BN254 (scripts/window_sweep.py: c = 17 at 2^20, 22 at 2^24)
     int best = 8;
     double best_cost = 1e300;
     for (int c = 6; c <= 23; c++) {
@@ -938,6 +939,12 @@ int choose_window_bits(int32_t curve, size_t n) {
             best_cost = cost;
             best = c;
         }
+    }
+    // BLS12-381: the 12-limb fold / fix-up tails weigh more than the model says around 2^20 points; measured
+    // (scripts/msm_probe_bls.py) 2^20: c = 16 5.3 ms, 18 5.5, 19 6.1; 2^21: c = 20 8.4 ms, 19 9.6, 18 9.6; 2^22: c = 20
+    if (curve != JFHIP_BN254) {
+        if (n <= ((size_t)3 << 19)) best = best < 16 ? best : 16;
+        else if (n <= ((size_t)3 << 21)) best = 20;
     }
     return best;
 }
@@ -965,13 +972,15 @@ static int32_t srs_build_table_t(jfhip_srs* srs, jfhip_stream* st) {
 
 // Which arithmetic the bucket accumulation of an SRS uses.  Measured on MI355X (BN254, uniform scalars): the 29-bit-limb
 // kernel is 17 % faster at 2^20 points (1.33 vs 1.60 ms) and 13 % slower at 2^24 (20.7 vs 18.3 ms; 12 GiB table, 49 % of
-// a wave's iterations cross a bucket boundary), so the default takes it up to 2^21 points.
-// JFHIP_MSM_F29=0 / 1 forces saturated / 29-bit limbs (A/B measurements).
-static bool use_f29(size_t n) {
+// a wave's iterations cross a bucket boundary); in between: 2^22 points 4.74 vs 5.29 ms, 2^23 points 11.4 vs 10.9 ms.
+// So the default takes it up to 2^22 points (+ the few extra SRS elements a circuit of that size needs).  BLS12-381
+// (14 limbs of 29 bits) is never faster than its saturated kernel (2^18: 0.94 vs 0.85 ms, 2^21: 6.1 vs 5.5, 2^22: 12.2
+// vs 11.0) and stays saturated.  JFHIP_MSM_F29=0 / 1 forces saturated / 29-bit limbs (A/B measurements).
+static bool use_f29(int32_t curve, size_t n) {
     const char* e = getenv("JFHIP_MSM_F29");
     if (e && e[0] == '0') return false;
     if (e && e[0] == '1') return true;
-    return n <= ((size_t)1 << 21);
+    return curve == JFHIP_BN254 && n <= ((size_t)1 << 22) + 4096;
 }
 
 int32_t srs_build_table(jfhip_srs* srs, const uint32_t* d_points_packed, jfhip_stream* st) {
@@ -980,7 +989,7 @@ int32_t srs_build_table(jfhip_srs* srs, const uint32_t* d_points_packed, jfhip_s
         JF_HIP(hipMemcpyAsync(srs->table, d_points_packed, srs->n * PT * 4, hipMemcpyDeviceToDevice, st->s));
     int32_t rc = (srs->curve == JFHIP_BN254) ? srs_build_table_t<Bn254G1>(srs, st) : srs_build_table_t<Bls381G1>(srs, st);
     if (rc != JFHIP_OK) return rc;
-    if (use_f29(srs->n)) {
+    if (use_f29(srs->curve, srs->n)) {
         // the whole table moves to the Montgomery factor of the 29-bit-limb arithmetic (fp29.hpp)
         JF_TRY(table_rescale(srs->curve, srs->table, (size_t)(srs->W > 0 ? srs->W : 1) * srs->n, 1, st->s));
         JF_HIP(hipStreamSynchronize(st->s));
