@@ -9,7 +9,7 @@ import pytest
 
 from oracle import coracle as C
 from oracle import pyref as R
-from tests.util import from_mont_arr, golden, h2i, mont_arr, rand_fr_mont, seeded_scalars
+from tests.util import from_mont_arr, golden, h2i, mont_arr, rand_fr_mont, ref_kat_cases, seeded_scalars
 
 pytestmark = pytest.mark.gpu
 CURVES = [R.BN254, R.BLS12_381]
@@ -34,6 +34,24 @@ def test_ntt_golden(hip, cv):
         evals_in = mont_arr(cv.fr, seeded_scalars(cv, seed ^ 0x5555, n)).reshape(1, n, 4)
         co = hip.ntt(cv.curve_id, evals_in, log_n, True, cos)
         assert hashlib.sha256(co.tobytes()).hexdigest() == case["inv_sha256"], case
+
+
+def test_intt_reference_known_answers(hip):
+    """jfhip_ntt(BLS12_381, inverse) against the literal ark-poly outputs the reference's own test asserts
+    (pcs/src/multilinear_kzg/util.rs:428-563): the one byte-level pin on arkworks' FFT convention that exists."""
+    cv = R.BLS12_381
+    cases, _ = ref_kat_cases()
+    for cite, log_n, evals, coeffs in cases:
+        data = mont_arr(cv.fr, evals).reshape(1, 1 << log_n, 4)
+        got = hip.ntt(cv.curve_id, data, log_n, True, None)
+        assert from_mont_arr(cv.fr, got) == coeffs, cite
+        assert (hip.ntt(cv.curve_id, got, log_n, False, None) == data).all(), cite
+    # the same vectors embedded (zero-extended evaluations are not what interpolate does; instead batch them)
+    four = [c for c in cases if c[1] == 2]
+    batch = np.stack([mont_arr(cv.fr, c[2]) for c in four])
+    got = hip.ntt(cv.curve_id, batch, 2, True, None)
+    for row, c in zip(got, four):
+        assert from_mont_arr(cv.fr, row) == c[3], c[0]
 
 
 @pytest.mark.parametrize("cv", CURVES, ids=lambda c: c.name)

@@ -7,7 +7,8 @@ import pytest
 
 from oracle import coracle as C
 from oracle import pyref as R
-from tests.util import FIELD_ID, from_mont_arr, golden, gpt, h2i, mont_arr, pt_arr, pt_from, rand_fr_mont, seeded_scalars
+from tests.util import (FIELD_ID, from_mont_arr, golden, gpt, h2i, mont_arr, pt_arr, pt_from, rand_fr_mont, ref_kat_cases,
+                        seeded_scalars)
 
 CURVES = [R.BN254, R.BLS12_381]
 
@@ -119,3 +120,23 @@ def test_commit_equals_p_of_beta_medium(cv):
     fa, fb, fs = (C.ntt(cv.curve_id, x, 12, False, cos) for x in (a, b, s))
     assert (C.fp_binop(0 if cv.curve_id == 0 else 2, "add", fa, fb) == fs).all()
     assert (C.ntt(cv.curve_id, fs, 12, True, cos) == s).all()
+
+
+def test_intt_reference_known_answers():
+    """The one place the reference holds literal ark-poly FFT outputs: test_build_l_helper,
+    pcs/src/multilinear_kzg/util.rs:428-563 (Evaluations::interpolate = domain.ifft, util.rs:177,184).  Pins the oracle's
+    root choice, ordering and n^-1 scaling of the inverse transform (and, through the round trip, the forward one)."""
+    cv = R.BLS12_381
+    cases, g = ref_kat_cases()
+    # the size-4 root the reference's comment names is the oracle's domain generator
+    assert R.domain_root(cv, 2) == h2i(g["size4_root_of_unity"])
+    assert from_mont_arr(cv.fr, C.domain_root(cv.curve_id, 2))[0] == h2i(g["size4_root_of_unity"])
+    for cite, log_n, evals, coeffs in cases:
+        # big-integer restatement
+        assert R.ifft(cv, evals, log_n) == coeffs, cite
+        assert R.fft(cv, coeffs, log_n) == evals, cite
+        # C restatement
+        data = mont_arr(cv.fr, evals).reshape(1, 1 << log_n, 4)
+        got = C.ntt(cv.curve_id, data, log_n, True, None)
+        assert from_mont_arr(cv.fr, got) == coeffs, cite
+        assert (C.ntt(cv.curve_id, got, log_n, False, None) == data).all(), cite

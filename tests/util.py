@@ -83,3 +83,18 @@ def rand_fr_mont(cv: R.Curve, n: int, seed: int) -> np.ndarray:
         fresh = rng.integers(0, 1 << 64, size=(bad.size, 4), dtype=np.uint64)
         fresh[:, 3] &= np.uint64((1 << (bits - 192)) - 1)
         out[bad] = fresh
+
+
+def ref_kat_cases():
+    """The reference-held iFFT known answers (tests/golden/ntt_ref_kat.json, transcribed from
+    pcs/src/multilinear_kzg/util.rs:428-563): -> list of (cite, log_n, evals, coeffs) as integers mod r."""
+    g = golden("ntt_ref_kat")
+    r = int(g["fr_modulus"])
+    assert r == R.BLS12_381.fr.p
+
+    def val(x):
+        if isinstance(x, list):
+            return int(x[0]) * pow(int(x[1]), -1, r) % r
+        return int(x) % r
+
+    return [(c["cite"], c["log_n"], [val(x) for x in c["evals"]], [val(x) for x in c["coeffs"]]) for c in g["cases"]], g
