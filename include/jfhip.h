@@ -253,6 +253,20 @@ int32_t jfhip_plonk_lookup_product_device(int32_t curve_id, uint32_t log_n, cons
 int32_t jfhip_poly_divide_linear_device(int32_t curve_id, const void *d_coeffs, size_t n, const uint64_t *point_mont,
                                         void *d_out, jfhip_stream *stream);
 
+/* The entry point that allocates nothing.  It has NO counterpart in the reference; it exists for callers that cannot
+ * allocate device memory: code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  Same
+ * arguments and same results as jfhip_poly_divide_linear_device, but the scan's workspace (chunk values, suffix arrays,
+ * per-level multipliers) is a static device array of 8.13 MiB that every GPU the library runs on holds until the process
+ * ends, the point travels as a kernel argument (no host->device copy), and the call makes no hipMalloc / hipFree or
+ * other allocating call, host or device.  Limits: n <= 2^23 coefficients (larger n: JFHIP_ERR_INVALID, use the call
+ * above); `stream` must be a handle made at set-up (NULL is JFHIP_ERR_INVALID, because the per-thread default stream is
+ * created on first use).  jfhip_init() on the device does the one-time set-up; without it the first call on a device
+ * does.  All calls on one GPU share that GPU's array: calls that overlap on one GPU (different streams or threads) race
+ * -- serialise them.  The array keeps the previous call's contents; the scan never reads an entry it has not written in
+ * the same call, so nothing needs clearing.  Asynchronous on `stream`. */
+int32_t jfhip_poly_divide_linear_noalloc_device(int32_t curve_id, const void *d_coeffs, size_t n,
+                                                const uint64_t *point_mont, void *d_out, jfhip_stream *stream);
+
 /* Replaces Prover::compute_evaluations / polynomial.evaluate (plonk/src/proof_system/prover.rs:205-229,
  * pcs/src/univariate_kzg/mod.rs:174): d_out[k] = d_polys[k](z) for `count` (<= 32) DEVICE polynomials at
  * one host point; d_out: count field elements on the device.  Asynchronous on `stream`. */

@@ -192,6 +192,8 @@ int32_t jfhip_init(int32_t device) {
         JF_HIP(hipSetDevice(device));
     }
     JF_HIP(hipFree(nullptr));
+    // set-up of the no-allocation entry point: this device's address of its static workspace
+    JF_TRY(noalloc_setup_current_device(nullptr));
     return JFHIP_OK;
 }
 
@@ -779,6 +781,23 @@ int32_t jfhip_poly_divide_linear_device(int32_t curve_id, const void* d_coeffs, 
     JF_HIP(hipMemcpyAsync(st->poly_a.p, point, 32, hipMemcpyHostToDevice, st->s));
     return open_witness_device(curve_id, (const uint32_t*)d_coeffs, n, st->poly_a.as<uint32_t>(), (uint32_t*)d_out,
                                nullptr, st);
+}
+
+int32_t jfhip_poly_divide_linear_noalloc_device(int32_t curve_id, const void* d_coeffs, size_t n, const uint64_t* point,
+                                                void* d_out, jfhip_stream* stream) {
+    JF_TRY(check_curve(curve_id));
+    if (!stream) {
+        // NULL would mean the per-thread default stream, which the library creates on first use: an allocation
+        set_error("no-alloc divide: pass a stream made at set-up (jfhip_stream_create / jfhip_stream_wrap)");
+        return JFHIP_ERR_INVALID;
+    }
+    if (n == 0) return JFHIP_OK;
+    if (!d_coeffs || !point || !d_out) {
+        set_error("null argument");
+        return JFHIP_ERR_INVALID;
+    }
+    std::lock_guard<std::mutex> lk(stream->mu);
+    return poly_divide_linear_noalloc(curve_id, (const uint32_t*)d_coeffs, n, point, (uint32_t*)d_out, stream->s);
 }
 
 int32_t jfhip_poly_eval_batch_device(int32_t curve_id, const void* const* d_polys, const size_t* lens, size_t count,

@@ -126,6 +126,9 @@ int32_t plonk_lookup_product_device(int32_t curve, uint32_t log_n, const uint32_
                                     jfhip_stream* st);
 int32_t open_witness_device(int32_t curve, const uint32_t* d_coeffs, size_t n, const uint32_t* d_point,
                             uint32_t* d_witness, uint32_t* d_eval, jfhip_stream* st);
+int32_t noalloc_setup_current_device(uint32_t** out);
+int32_t poly_divide_linear_noalloc(int32_t curve, const uint32_t* d_coeffs, size_t n, const uint64_t* point_mont,
+                                   uint32_t* d_out, hipStream_t stream);
 int32_t witness_gather_device(const uint32_t* d_witness, size_t num_vars, const uint32_t* d_wire_variables, size_t count,
                               uint32_t* d_out, jfhip_stream* st);
 int32_t poly_lincomb_device(int32_t curve, const uint32_t* const* d_polys, const size_t* lens, size_t count,

@@ -60,24 +60,62 @@ __global__ void k_horner_mus(const uint32_t* __restrict__ z, uint32_t levels, ui
     }
 }
 
+// By-value field element for kernels whose scalar argument must not pass through device memory first.
+struct FrArg {
+    uint32_t v[8];
+};
 template <class Fr>
-static int32_t open_witness_t(const uint32_t* d_coeffs, size_t n, const uint32_t* d_point, uint32_t* d_suffix,
-                              jfhip_stream* st) {
-    // d_suffix receives s_0 .. s_{n-1}; the witness is d_suffix + one element, eval is s_0
-    constexpr int N = Fr::N;
-    // level sizes
-    std::vector<size_t> sizes;
-    sizes.push_back(n);
-    while (sizes.back() > HORNER_K) sizes.push_back((sizes.back() + HORNER_K - 1) / HORNER_K);
-    const uint32_t levels = (uint32_t)sizes.size();
+__global__ void k_horner_mus_val(FrArg z, uint32_t levels, uint32_t* __restrict__ mus) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    Fp<Fr> mu;
+    for (int i = 0; i < Fr::N; i++) mu.v[i] = z.v[i];
+    for (uint32_t l = 0; l < levels; l++) {
+        fp_store<Fr>(mus + (size_t)l * Fr::N, mu);
+        mu = fp_pow_u64<Fr>(mu, HORNER_K);
+    }
+}
+
+constexpr uint32_t HORNER_MAX_LEVELS = 8;  // 64^8 > 2^32 coefficients
+
+// level sizes of the chunked scan over n coefficients; returns the number of levels
+static inline uint32_t horner_levels(size_t n, size_t* sizes) {
+    uint32_t levels = 0;
+    sizes[levels++] = n;
+    while (sizes[levels - 1] > HORNER_K && levels < HORNER_MAX_LEVELS) {
+        sizes[levels] = (sizes[levels - 1] + HORNER_K - 1) / HORNER_K;
+        levels++;
+    }
+    return levels;
+}
+// 32-bit words of workspace the scan over n coefficients needs (chunk values + their suffix arrays of levels 1..,
+// one multiplier per level)
+static inline size_t horner_workspace_words(size_t n) {
+    size_t sizes[HORNER_MAX_LEVELS];
+    const uint32_t levels = horner_levels(n, sizes);
     size_t extra = 0;
     for (uint32_t l = 1; l < levels; l++) extra += sizes[l];
-    JF_TRY(st->poly_b.ensure((extra * 2 + levels + 1) * N * 4));
-    uint32_t* hbuf = st->poly_b.as<uint32_t>();          // chunk values of levels 1..
-    uint32_t* sbuf = hbuf + extra * N;                    // their suffix arrays
+    return (extra * 2 + levels + 1) * 8;
+}
+
+// The scan itself on a caller-provided workspace `ws` (horner_workspace_words(n) words).  The point comes either from
+// device memory (d_point) or by value (z_val, when d_point is NULL).  Allocates nothing, host or device.
+template <class Fr>
+static int32_t open_witness_ws(const uint32_t* d_coeffs, size_t n, const uint32_t* d_point, const FrArg* z_val,
+                               uint32_t* ws, uint32_t* d_suffix, hipStream_t stream) {
+    // d_suffix receives s_0 .. s_{n-1}; the witness is d_suffix + one element, eval is s_0
+    constexpr int N = Fr::N;
+    size_t sizes[HORNER_MAX_LEVELS];
+    const uint32_t levels = horner_levels(n, sizes);
+    size_t extra = 0;
+    for (uint32_t l = 1; l < levels; l++) extra += sizes[l];
+    uint32_t* hbuf = ws;                // chunk values of levels 1..
+    uint32_t* sbuf = hbuf + extra * N;  // their suffix arrays
     uint32_t* mus = sbuf + extra * N;
-    hipLaunchKernelGGL((k_horner_mus<Fr>), dim3(1), dim3(64), 0, st->s, d_point, levels, mus);
-    std::vector<uint32_t*> h(levels), s(levels);
+    if (d_point)
+        hipLaunchKernelGGL((k_horner_mus<Fr>), dim3(1), dim3(64), 0, stream, d_point, levels, mus);
+    else
+        hipLaunchKernelGGL((k_horner_mus_val<Fr>), dim3(1), dim3(64), 0, stream, *z_val, levels, mus);
+    uint32_t *h[HORNER_MAX_LEVELS], *s[HORNER_MAX_LEVELS];
     h[0] = const_cast<uint32_t*>(d_coeffs);
     s[0] = d_suffix;
     size_t o = 0;
@@ -88,7 +126,7 @@ static int32_t open_witness_t(const uint32_t* d_coeffs, size_t n, const uint32_t
     }
     for (uint32_t l = 1; l < levels; l++) {
         unsigned blocks = (unsigned)((sizes[l] + 127) / 128);
-        hipLaunchKernelGGL((k_horner_chunks<Fr>), dim3(blocks), dim3(128), 0, st->s, h[l - 1], (uint32_t)sizes[l - 1],
+        hipLaunchKernelGGL((k_horner_chunks<Fr>), dim3(blocks), dim3(128), 0, stream, h[l - 1], (uint32_t)sizes[l - 1],
                            mus + (size_t)(l - 1) * N, h[l]);
     }
     for (uint32_t l = levels; l-- > 0;) {
@@ -96,7 +134,7 @@ static int32_t open_witness_t(const uint32_t* d_coeffs, size_t n, const uint32_t
         unsigned blocks = (unsigned)((chunks + 127) / 128);
         const uint32_t* carry = (l + 1 < levels) ? s[l + 1] : nullptr;
         uint32_t n_carry = (l + 1 < levels) ? (uint32_t)sizes[l + 1] : 0u;
-        hipLaunchKernelGGL((k_horner_apply<Fr>), dim3(blocks), dim3(128), 0, st->s, h[l], (uint32_t)sizes[l],
+        hipLaunchKernelGGL((k_horner_apply<Fr>), dim3(blocks), dim3(128), 0, stream, h[l], (uint32_t)sizes[l],
                            mus + (size_t)l * N, carry, n_carry, s[l]);
     }
     JF_HIP(hipGetLastError());
@@ -108,8 +146,72 @@ int32_t open_witness_device(int32_t curve, const uint32_t* d_coeffs, size_t n, c
     // d_witness: n elements of scratch-and-result: [0] = eval, [1..n) = witness coefficients
     (void)d_eval;
     if (n == 0) return JFHIP_OK;
-    if (curve == JFHIP_BN254) return open_witness_t<Bn254Fr>(d_coeffs, n, d_point, d_witness, st);
-    return open_witness_t<Bls381Fr>(d_coeffs, n, d_point, d_witness, st);
+    if (n >= ((size_t)1 << 32)) {
+        set_error("divide: polynomial too long");
+        return JFHIP_ERR_INVALID;
+    }
+    JF_TRY(st->poly_b.ensure(horner_workspace_words(n) * 4));
+    uint32_t* ws = st->poly_b.as<uint32_t>();
+    if (curve == JFHIP_BN254) return open_witness_ws<Bn254Fr>(d_coeffs, n, d_point, nullptr, ws, d_witness, st->s);
+    return open_witness_ws<Bls381Fr>(d_coeffs, n, d_point, nullptr, ws, d_witness, st->s);
+}
+
+// ---- the entry point that allocates nothing (jfhip_poly_divide_linear_noalloc_device) ------------------------------
+// For callers that cannot call hipMalloc (HIP graph capture, tight serving loops, harnesses that forbid it): the same
+// chunked scan as above with its workspace (chunk values, suffix arrays, per-level multipliers) in a file-scope device
+// array instead of the stream's grow-only DevBuf.  Every GPU holds its own copy of the array at its own address; the
+// address is taken once per device with hipGetSymbolAddress and only that pointer is ever handed to kernels (the array's
+// name in host code is a host-side stand-in, not a device address).
+constexpr size_t NOALLOC_MAX_N = (size_t)1 << 23;
+// levels of 2^23 coefficients: 131072 + 2048 + 32 chunk values, twice (values + suffixes), + 5 multipliers
+constexpr size_t NOALLOC_SCRATCH_WORDS = ((131072 + 2048 + 32) * 2 + 5) * 8;  // 8.13 MiB
+static __device__ __align__(256) uint32_t scratch[NOALLOC_SCRATCH_WORDS];
+
+constexpr int NOALLOC_MAX_DEVICES = 64;
+static std::mutex g_noalloc_mu;
+static uint32_t* g_noalloc_ptr[NOALLOC_MAX_DEVICES] = {};
+
+// once per device, with that device current: the device address of this GPU's copy of `scratch`
+int32_t noalloc_setup_current_device(uint32_t** out) {
+    int dev = -1;
+    JF_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= NOALLOC_MAX_DEVICES) {
+        set_error("no-alloc entry point: device ordinal %d beyond the %d supported", dev, NOALLOC_MAX_DEVICES);
+        return JFHIP_ERR_INVALID;
+    }
+    std::lock_guard<std::mutex> lk(g_noalloc_mu);
+    if (!g_noalloc_ptr[dev]) {
+        uint32_t* ptr = nullptr;
+        JF_HIP(hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch)));
+        if (!ptr) {
+            set_error("hipGetSymbolAddress(scratch) returned a null address on device %d", dev);
+            return JFHIP_ERR_DEVICE;
+        }
+        g_noalloc_ptr[dev] = ptr;
+    }
+    if (out) *out = g_noalloc_ptr[dev];
+    return JFHIP_OK;
+}
+
+int32_t poly_divide_linear_noalloc(int32_t curve, const uint32_t* d_coeffs, size_t n, const uint64_t* point_mont,
+                                   uint32_t* d_out, hipStream_t stream) {
+    if (n > NOALLOC_MAX_N) {
+        set_error("no-alloc divide: %zu coefficients exceed the fixed workspace (at most %zu); use "
+                  "jfhip_poly_divide_linear_device", n, NOALLOC_MAX_N);
+        return JFHIP_ERR_INVALID;
+    }
+    if (horner_workspace_words(n) > NOALLOC_SCRATCH_WORDS) {  // cannot happen for n <= NOALLOC_MAX_N; host-side guard
+        set_error("no-alloc divide: workspace bound violated for n = %zu", n);
+        return JFHIP_ERR_INVALID;
+    }
+    uint32_t* ptr = nullptr;
+    JF_TRY(noalloc_setup_current_device(&ptr));
+    FrArg z;
+    memcpy(z.v, point_mont, 32);
+    // nothing in the workspace has to start at zero: every level writes its chunk values and suffixes before the next
+    // kernel reads them, and the top chunk's carry is the constant 0, not a stored value
+    if (curve == JFHIP_BN254) return open_witness_ws<Bn254Fr>(d_coeffs, n, nullptr, &z, ptr, d_out, stream);
+    return open_witness_ws<Bls381Fr>(d_coeffs, n, nullptr, &z, ptr, d_out, stream);
 }
 
 // ---- batched evaluation at one point --------------------------------------------------------------
