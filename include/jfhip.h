@@ -243,6 +243,18 @@ int32_t jfhip_plonk_lookup_product_device(int32_t curve_id, uint32_t log_n, cons
                                           const void *d_table, const void *d_sorted, const uint64_t *beta_mont,
                                           const uint64_t *gamma_mont, void *d_out, jfhip_stream *stream);
 
+/* Replaces Arithmetization::compute_merged_lookup_table and the merged_lookup_wire_value calls of
+ * compute_lookup_sorted_vec_polynomials / compute_lookup_prod_polynomial (relation/src/constraint_system.rs:1495-1514,
+ * 1552-1553, 1601-1602, helpers :1648-1687) on DEVICE data, for every row i of the size-2^log_n domain:
+ *     d_merged_table[i]  = range[i] + q_lookup[i] tau (table_dom_sep[i] + tau (key[i] + tau (w3[i] + tau w4[i])))
+ *     d_merged_lookup[i] = w5[i]    + q_lookup[i] tau (q_dom_sep[i]     + tau (w0[i]  + tau (w1[i] + tau w2[i])))
+ * d_wire_vals: [6][n] witness values per wire type (what jfhip_witness_gather_device leaves); d_table_vals: [5][n] rows
+ * range_table, key_table, table_dom_sep, q_dom_sep, q_lookup (values on H, fixed by the circuit); tau: host, Montgomery.
+ * Asynchronous on `stream`. */
+int32_t jfhip_plonk_lookup_merge_device(int32_t curve_id, uint32_t log_n, const void *d_wire_vals,
+                                        const void *d_table_vals, const uint64_t *tau_mont, void *d_merged_table,
+                                        void *d_merged_lookup, jfhip_stream *stream);
+
 /* ---- device-resident polynomial glue (next row) -------------------------- */
 
 /* Replaces the witness-polynomial division of open() / compute_batched_witness_polynomial_commitment

@@ -767,6 +767,20 @@ int32_t jfhip_plonk_lookup_product_device(int32_t curve_id, uint32_t log_n, cons
                                        (const uint32_t*)d_sorted, beta, gamma, (uint32_t*)d_out, st);
 }
 
+int32_t jfhip_plonk_lookup_merge_device(int32_t curve_id, uint32_t log_n, const void* d_wire_vals,
+                                        const void* d_table_vals, const uint64_t* tau, void* d_merged_table,
+                                        void* d_merged_lookup, jfhip_stream* stream) {
+    JF_TRY(check_curve(curve_id));
+    if (!d_wire_vals || !d_table_vals || !tau || !d_merged_table || !d_merged_lookup) {
+        set_error("null argument");
+        return JFHIP_ERR_INVALID;
+    }
+    JF_STREAM(st, stream);
+    std::lock_guard<std::mutex> lk(st->mu);
+    return plonk_lookup_merge_device(curve_id, log_n, (const uint32_t*)d_wire_vals, (const uint32_t*)d_table_vals, tau,
+                                     (uint32_t*)d_merged_table, (uint32_t*)d_merged_lookup, st);
+}
+
 int32_t jfhip_poly_divide_linear_device(int32_t curve_id, const void* d_coeffs, size_t n, const uint64_t* point,
                                         void* d_out, jfhip_stream* stream) {
     JF_TRY(check_curve(curve_id));

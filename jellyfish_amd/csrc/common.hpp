@@ -124,6 +124,8 @@ int32_t plonk_perm_product_device(int32_t curve, uint32_t log_n, uint32_t nw, co
 int32_t plonk_lookup_product_device(int32_t curve, uint32_t log_n, const uint32_t* f, const uint32_t* t,
                                     const uint32_t* s, const uint64_t* beta, const uint64_t* gamma, uint32_t* out,
                                     jfhip_stream* st);
+int32_t plonk_lookup_merge_device(int32_t curve, uint32_t log_n, const uint32_t* wires, const uint32_t* tabs,
+                                  const uint64_t* tau, uint32_t* out_table, uint32_t* out_lookup, jfhip_stream* st);
 int32_t open_witness_device(int32_t curve, const uint32_t* d_coeffs, size_t n, const uint32_t* d_point,
                             uint32_t* d_witness, uint32_t* d_eval, jfhip_stream* st);
 int32_t noalloc_setup_current_device(uint32_t** out);

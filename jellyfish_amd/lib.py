@@ -35,7 +35,7 @@ SYMBOLS = [
     "jfhip_stream_sync", "jfhip_stream_raw", "jfhip_stream_wrap", "jfhip_srs_load", "jfhip_srs_load_device",
     "jfhip_srs_gen_for_testing", "jfhip_srs_free", "jfhip_srs_len", "jfhip_srs_window_bits", "jfhip_srs_read",
     "jfhip_msm", "jfhip_msm_batch", "jfhip_msm_batch_device", "jfhip_msm_device", "jfhip_msm_partial_device", "jfhip_g1_sum_partials",
-    "jfhip_kzg_open", "jfhip_ntt", "jfhip_ntt_device", "jfhip_plonk_quotient_turbo_device", "jfhip_plonk_quotient_ultra_device", "jfhip_plonk_quotient_coset_device", "jfhip_plonk_quotient_masked_device", "jfhip_plonk_perm_product_device", "jfhip_plonk_lookup_product_device", "jfhip_witness_gather_device", "jfhip_poly_divide_linear_device", "jfhip_poly_divide_linear_noalloc_device",
+    "jfhip_kzg_open", "jfhip_ntt", "jfhip_ntt_device", "jfhip_plonk_quotient_turbo_device", "jfhip_plonk_quotient_ultra_device", "jfhip_plonk_quotient_coset_device", "jfhip_plonk_quotient_masked_device", "jfhip_plonk_perm_product_device", "jfhip_plonk_lookup_product_device", "jfhip_plonk_lookup_merge_device", "jfhip_witness_gather_device", "jfhip_poly_divide_linear_device", "jfhip_poly_divide_linear_noalloc_device",
     "jfhip_poly_lincomb_device", "jfhip_poly_eval_batch_device", "jfhip_field_op", "jfhip_g1_op", "jfhip_probe",
     "jfhip_set_profiling", "jfhip_last_phase_ms", "jfhip_phase_name", "jfhip_keccak_f1600",
 ]
@@ -335,6 +335,14 @@ def plonk_lookup_product_device(curve: int, log_n: int, d_lookup_wire: int, d_ta
     b, g = _u64(beta_mont), _u64(gamma_mont)
     _check(load_library().jfhip_plonk_lookup_product_device(curve, log_n, _vp(d_lookup_wire), _vp(d_table), _vp(d_sorted),
                                                             _p(b), _p(g), _vp(d_out), _sh(stream)))
+
+
+def plonk_lookup_merge_device(curve: int, log_n: int, d_wire_vals: int, d_table_vals: int, tau_mont, d_merged_table: int,
+                              d_merged_lookup: int, stream: Stream | None = None):
+    """Plookup merged table / merged lookup witness values on H (see include/jfhip.h)"""
+    t = _u64(tau_mont)
+    _check(load_library().jfhip_plonk_lookup_merge_device(curve, log_n, _vp(d_wire_vals), _vp(d_table_vals), _p(t),
+                                                          _vp(d_merged_table), _vp(d_merged_lookup), _sh(stream)))
 
 
 def poly_divide_linear_device(curve: int, d_coeffs: int, n: int, point_mont, d_out: int, stream: Stream | None = None):

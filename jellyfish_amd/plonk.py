@@ -1,4 +1,5 @@
-"""TurboPlonk `PlonkKzgSnark::{preprocess, prove}` with every polynomial operation on the device.
+"""TurboPlonk / UltraPlonk (Plookup) `PlonkKzgSnark::{preprocess, prove, batch_prove}` with every polynomial operation on
+the device.
 
 Host-side mirror of the reference interface (same names, argument meaning and error behaviour):
   * `PlonkCircuit`                       relation/src/constraint_system.rs:347-470, 558-790, 831-884, 943-981, 1116-1187
@@ -6,6 +7,10 @@ Host-side mirror of the reference interface (same names, argument meaning and er
                                           plonk/src/proof_system/snark.rs:447-488, 492-580, 587-613 (-> 163-430)
   * prover rounds                         plonk/src/proof_system/prover.rs:77-91, 128-142, 183-229, 299-413, 457-488,
                                           491-661, 894-1015
+  * UltraPlonk / Plookup                  circuit: relation/src/constraint_system.rs:304-312, 445-481, 604-648, 845-864,
+                                          1171-1179, 1460-1688, gadgets/ultraplonk/lookup_table.rs:21-71;
+                                          rounds 1.5 / 2.5 / 4.5: snark.rs:254-318, 346-362, prover.rs:99-124, 147-178,
+                                          233-296, 421-453, 766-882, 1017-1087; PlookupProof structs.rs:208-221, 460-536
 The host keeps what the reference keeps on one thread: the Merlin transcript (`StandardTranscript`), the RNG draws for
 the blinding factors (same order), a handful of scalar formulas.  Everything that touches a polynomial runs in libjfhip on
 the GPU and stays resident in HBM between rounds: witness gather, iNTTs, blinding, the permutation grand product, 25
@@ -29,6 +34,13 @@ from .transcript import MerlinTranscript
 
 GATE_WIDTH = 4
 N_TURBO_PLONK_SELECTORS = 13
+# UltraPlonk wire roles (relation/src/constraint_system.rs:304-312)
+RANGE_WIRE_ID = 5
+LOOKUP_KEY_WIRE_ID, LOOKUP_VAL_1_WIRE_ID, LOOKUP_VAL_2_WIRE_ID = 0, 1, 2
+TABLE_VAL_1_WIRE_ID, TABLE_VAL_2_WIRE_ID = 3, 4
+# an UltraPlonk gate kind = 13 selectors + (q_lookup, q_dom_sep, table_key, table_dom_sep)   (gates/mod.rs:55-69)
+_NO_LOOKUP = (0, 0, 0, 0)
+_Q_LOOKUP, _Q_DOM_SEP, _TABLE_KEY, _TABLE_DOM_SEP = 13, 14, 15, 16
 
 
 class PlonkError(RuntimeError):
@@ -43,16 +55,20 @@ def _sel(q_lc=(0, 0, 0, 0), q_mul=(0, 0), q_hash=(0, 0, 0, 0), q_o=0, q_c=0, q_e
 
 
 class PlonkCircuit:
-    """TurboPlonk constraint system (host side).  Variables 0 / 1 hold the constants 0 / 1."""
+    """TurboPlonk / UltraPlonk constraint system (host side).  Variables 0 / 1 hold the constants 0 / 1."""
 
-    def __init__(self, curve: int):
+    def __init__(self, curve: int, range_bit_len: int | None = None):
         self.cp = H.CURVES[curve]
         self.r = self.cp.r
-        self.num_wire_types = GATE_WIDTH + 1
+        self.ultra = range_bit_len is not None
+        self._range_bit_len = range_bit_len
+        self.num_wire_types = GATE_WIDTH + 1 + (1 if self.ultra else 0)
         self.witness: list[int] = [0, 1]
         self._gates: list[tuple] = []
-        self._wires: list[list[int]] = [[] for _ in range(GATE_WIDTH + 1)]
+        self._wires: list[list[int]] = [[] for _ in range(self.num_wire_types)]
         self.pub_input_gate_ids: list[int] = []
+        self._table_gate_ids: list[tuple] = []
+        self._num_table_elems = 0
         self._n = 0
         self.enforce_constant(0, 0)
         self.enforce_constant(1, 1)
@@ -61,21 +77,37 @@ class PlonkCircuit:
     def new_turbo_plonk(cls, curve: int) -> "PlonkCircuit":
         return cls(curve)
 
+    @classmethod
+    def new_ultra_plonk(cls, curve: int, range_bit_len: int) -> "PlonkCircuit":
+        """constraint_system.rs:445-448"""
+        return cls(curve, range_bit_len)
+
+    def support_lookup(self) -> bool:
+        return self.ultra
+
+    def range_bit_len(self) -> int:
+        if not self.ultra:
+            raise PlonkError("call range_bit_len() with non-ultraplonk circuit")
+        return self._range_bit_len
+
+    def range_size(self) -> int:
+        return 1 << self.range_bit_len()
+
     # ---- builder ---------------------------------------------------------------------------------
     def _check_var(self, *vs):
         for v in vs:
             if not 0 <= v < len(self.witness):
                 raise PlonkError("VarIndexOutOfBound(%d, %d)" % (v, len(self.witness)))
 
-    def _insert_gate(self, wire_vars, sel):
+    def _insert_gate(self, wire_vars, sel, lk=_NO_LOOKUP):
         if self._n:
             raise PlonkError("ModifyFinalizedCircuit")
-        for w, v in zip(self._wires, wire_vars):
+        for w, v in zip(self._wires, wire_vars):      # the GATE_WIDTH + 1 gate wires; the range wire has its own list
             w.append(v)
-        self._gates.append(sel)
+        self._gates.append(sel + lk if self.ultra else sel)
 
     def num_gates(self) -> int:
-        return len(self._gates)
+        return len(self._gates) if not self._n else int(self.gate_kind.size)
 
     def num_vars(self) -> int:
         return len(self.witness)
@@ -163,6 +195,31 @@ class PlonkCircuit:
         for _ in range(n):
             self._insert_gate((0, 0, 0, 0, 0), _sel(q_lc=(1, self.r - 1, 0, 0), q_o=1))
 
+    def add_range_check_variable(self, var: int):
+        """the variable joins the range wire and is looked up in [0, range_size) (constraint_system.rs:475-481)"""
+        if not self.ultra:
+            raise PlonkError("WrongPlonkType")
+        if self._n:
+            raise PlonkError("ModifyFinalizedCircuit")
+        self._check_var(var)
+        self._wires[RANGE_WIRE_ID].append(var)
+
+    def create_table_and_lookup_variables(self, lookup_vars, table_vars):
+        """a key-value table (keys 0 .. len-1, values = pairs of variables) and (key, val0, val1) variable triples to look
+        up in it: one LookupGate per row (relation/src/gadgets/ultraplonk/lookup_table.rs:21-71)"""
+        if not self.ultra:
+            raise PlonkError("WrongPlonkType")
+        for t in list(lookup_vars) + list(table_vars):
+            self._check_var(*t)
+        cnt = max(len(lookup_vars), len(table_vars))
+        self._table_gate_ids.append((self.num_gates(), cnt))
+        table_ctr = len(self._table_gate_ids)
+        for i in range(cnt):
+            q_dom_sep, (key, val0, val1) = (table_ctr, lookup_vars[i]) if i < len(lookup_vars) else (0, (0, 0, 0))
+            table_dom_sep, table_key, (tv0, tv1) = (table_ctr, i, table_vars[i]) if i < len(table_vars) else (0, 0, (0, 0))
+            self._insert_gate((key, val0, val1, tv0, tv1), _sel(), lk=(1, q_dom_sep, table_key, table_dom_sep))
+        self._num_table_elems += cnt
+
     def public_input(self) -> list[int]:
         out = self._wires[GATE_WIDTH] if not self._n else self.wire_variables[GATE_WIDTH]
         return [self.witness[int(out[g])] for g in self.pub_input_gate_ids]
@@ -180,29 +237,42 @@ class PlonkCircuit:
         return self.eval_domain_size() + 2
 
     def finalize_for_arithmetization(self):
-        """pad to a power of two, io gates to the front, wire permutation (constraint_system.rs:1167-1187);
-        the field-valued tables (k * g^j, sigma values, selector polynomials) are built on the device by preprocess"""
+        """pad to a power of two, io gates to the front, table lookup gates to the rear, wire permutation
+        (constraint_system.rs:1167-1187); the field-valued tables (k * g^j, sigma values, selector polynomials) are built
+        on the device by preprocess"""
         if self._n:
             return
+        slots = self.num_gates()
+        if self.ultra:   # range gates and lookup gates need separate slots (:1171-1179)
+            slots = max(slots, max(self.range_size(), len(self._wires[RANGE_WIRE_ID])) + self._num_table_elems + 1)
         n = 1
-        while n < self.num_gates():
+        while n < slots:
             n <<= 1
         if n.bit_length() - 1 > self.cp.two_adicity:
             raise PlonkError("DomainCreationError")
         W = self.num_wire_types
-        pad = n - self.num_gates()
         wv = np.zeros((W, n), dtype=np.int64)
         for i in range(W):
-            wv[i, :n - pad] = self._wires[i]
-        gates = self._gates + [_sel()] * pad
+            wv[i, :len(self._wires[i])] = self._wires[i]
+        gates = self._gates + [_sel() + (_NO_LOOKUP if self.ultra else ())] * (n - len(self._gates))
         uniq: dict[tuple, int] = {}
         gate_kind = np.fromiter((uniq.setdefault(g, len(uniq)) for g in gates), dtype=np.int64, count=n)
+        GW = GATE_WIDTH + 1   # rearrange_gates swaps the gate wires only; the range wire stays (:836-840, 855-859)
         for gate_id in range(len(self.pub_input_gate_ids)):
             io = self.pub_input_gate_ids[gate_id]
             if io > gate_id:
                 gate_kind[[gate_id, io]] = gate_kind[[io, gate_id]]
-                wv[:, [gate_id, io]] = wv[:, [io, gate_id]]
+                wv[:GW, [gate_id, io]] = wv[:GW, [io, gate_id]]
                 self.pub_input_gate_ids[gate_id] = gate_id
+        if self.ultra:
+            # table lookup gates to the rear, never the very last slot, relative order kept (:845-864)
+            cur = n - 2
+            for table_gate_id, table_size in reversed(self._table_gate_ids):
+                for gate_id in range(table_gate_id + table_size - 1, table_gate_id - 1, -1):
+                    if gate_id < cur:
+                        gate_kind[[gate_id, cur]] = gate_kind[[cur, gate_id]]
+                        wv[:GW, [gate_id, cur]] = wv[:GW, [cur, gate_id]]
+                        cur -= 1
         # wire permutation: the wires of one variable, in (wire type, gate) order, form a cycle
         flat = wv.reshape(-1)
         order = np.argsort(flat, kind="stable")
@@ -226,18 +296,34 @@ class PlonkCircuit:
         self.log_n = n.bit_length() - 1
 
     def check_circuit_satisfiability(self, pub_input) -> None:
-        """gate equation on every row (constraint_system.rs:585-603, 894-938); host integers, for tests/small circuits"""
+        """gate equation on every row, range gates and key-value lookups (constraint_system.rs:585-650, 894-938); host
+        integers, for tests / small circuits"""
         if len(pub_input) != self.num_inputs():
             raise PlonkError("PubInputLenMismatch(%d, %d)" % (len(pub_input), self.num_inputs()))
         r = self.r
         pis = dict(zip(self.pub_input_gate_ids, pub_input))
+        wit = lambda i, g: self.witness[int(self.wire_variables[i][g])]   # noqa: E731
         for gid in range(self._n):
             s = self.gate_kinds[int(self.gate_kind[gid])]
-            w = [self.witness[int(self.wire_variables[i][gid])] for i in range(5)]
+            w = [wit(i, gid) for i in range(5)]
             lhs = (pis.get(gid, 0) + sum(s[i] * w[i] for i in range(4)) + s[4] * w[0] * w[1] + s[5] * w[2] * w[3]
                    + sum(s[6 + i] * pow(w[i], 5, r) for i in range(4)) + s[11] + s[12] * w[0] * w[1] * w[2] * w[3] * w[4])
             if (lhs - s[10] * w[4]) % r:
                 raise PlonkError("GateCheckFailure(%d)" % gid)
+        if not self.ultra:
+            return
+        for gid in range(self._n):
+            if wit(RANGE_WIRE_ID, gid) >= self.range_size():
+                raise PlonkError("GateCheckFailure(%d): Range gate failed" % gid)
+        table = {(0, 0, 0, 0)}
+        kinds = [self.gate_kinds[int(k)] for k in self.gate_kind]
+        for gid, s in enumerate(kinds):
+            if s[_Q_LOOKUP]:
+                table.add((s[_TABLE_DOM_SEP], s[_TABLE_KEY], wit(TABLE_VAL_1_WIRE_ID, gid), wit(TABLE_VAL_2_WIRE_ID, gid)))
+        for gid, s in enumerate(kinds):
+            if s[_Q_LOOKUP] and (s[_Q_DOM_SEP], wit(LOOKUP_KEY_WIRE_ID, gid), wit(LOOKUP_VAL_1_WIRE_ID, gid),
+                                 wit(LOOKUP_VAL_2_WIRE_ID, gid)) not in table:
+                raise PlonkError("GateCheckFailure(%d): Lookup gate failed" % gid)
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -266,23 +352,36 @@ class VerifyingKey:
     h: tuple
     beta_h: tuple
     is_merged: bool = False
+    # PlookupVerifyingKey (structs.rs:736-753): range_table_comm, key_table_comm, table_dom_sep_comm, q_dom_sep_comm
+    plookup_vk: dict | None = None
 
     def as_dict(self) -> dict:
-        return dict(domain_size=self.domain_size, num_inputs=self.num_inputs, sigma_comms=self.sigma_comms,
-                    selector_comms=self.selector_comms, k=self.k, g=self.g, h=self.h, beta_h=self.beta_h)
+        d = dict(domain_size=self.domain_size, num_inputs=self.num_inputs, sigma_comms=self.sigma_comms,
+                 selector_comms=self.selector_comms, k=self.k, g=self.g, h=self.h, beta_h=self.beta_h)
+        if self.plookup_vk is not None:
+            d["plookup_vk"] = dict(self.plookup_vk)
+        return d
 
 
 @dataclass
 class ProvingKey:
     curve: int
     sigmas: torch.Tensor          # (W, n*4) coefficients
-    selectors: torch.Tensor       # (13, n*4) coefficients
+    selectors: torch.Tensor       # (13 or 14, n*4) coefficients; UltraPlonk: q_lookup last
     commit_key: "L.Srs"
     vk: VerifyingKey
     # evaluation-form tables the grand product reads (the reference recomputes them from the circuit per proof)
     id_perm_vals: torch.Tensor = field(repr=False, default=None)
     sigma_vals: torch.Tensor = field(repr=False, default=None)
     wire_variables: torch.Tensor = field(repr=False, default=None)
+    # PlookupProvingKey (structs.rs:558-573), UltraPlonk only: coefficients of range_table, key_table, table_dom_sep,
+    # q_dom_sep (4, n*4), and the same four vectors + q_lookup in evaluation form (5, n*4) for the merged-vector kernel
+    plookup_polys: torch.Tensor = field(repr=False, default=None)
+    plookup_table_vals: torch.Tensor = field(repr=False, default=None)
+
+    @property
+    def supports_lookup(self) -> bool:
+        return self.plookup_polys is not None
 
     @property
     def wire_variables32(self) -> torch.Tensor:
@@ -290,9 +389,9 @@ class ProvingKey:
         if getattr(self, "_wv32", None) is None:
             self._wv32 = self.wire_variables.to(torch.int32).contiguous()
         return self._wv32
-    # optional: the 13 selector + W sigma polynomials evaluated on the quotient coset (m = 8n points each), kept in HBM.
-    # The reference recomputes these 18 coset FFTs in every proof (prover.rs:534-544); they depend on the proving key
-    # only, and 288 GB of HBM holds them (18 x 256 MiB at n = 2^20).  Same values, so the same proof bytes.
+    # optional: the selector + sigma (+ 4 Plookup table) polynomials evaluated on the quotient coset (m = 8n points each),
+    # kept in HBM.  The reference recomputes these 18 (24) coset FFTs in every proof (prover.rs:534-567); they depend on the
+    # proving key only, and 288 GB of HBM holds them (18 x 256 MiB at n = 2^20).  Same values, so the same proof bytes.
     coset_evals: torch.Tensor = field(repr=False, default=None)
     coset_slice: tuple = (0, 1)   # (rank, world) the resident evaluations were computed for
     # selector polynomials that are identically zero for this circuit (a gate kind it never uses): their coset
@@ -310,23 +409,101 @@ class ProvingKey:
         return m
 
     def keep_coset_evals(self, stream=None, rank: int = 0, world: int = 1) -> "ProvingKey":
-        """evaluate selectors and sigmas on the quotient coset once and keep them resident (see coset_evals).
-        world > 1: only rank's slice of the coset (prove(sharded=True) with coset sharding, see quotient_slices)"""
+        """evaluate selectors, sigmas (and the Plookup tables) on the quotient coset once and keep them resident (see
+        coset_evals).  world > 1: only rank's slice of the coset (prove(sharded=True) with coset sharding)"""
         cp = H.CURVES[self.curve]
         n, m = self.vk.domain_size, self.quot_domain_size()
         if not coset_sharding_applies(n, m, world):
             rank, world = 0, 1
         ml = m // world
         nsel, W = self.selectors.shape[0], self.sigmas.shape[0]
-        ev = torch.empty(nsel + W, ml * 4, dtype=torch.int64, device="cuda")
-        ev[:nsel, :n * 4].copy_(self.selectors)
-        ev[nsel:, :n * 4].copy_(self.sigmas)
-        off = H.fr_to_mont(cp, [slice_offset(cp, m, rank)])[0]
-        L.ntt_device(self.curve, ev.data_ptr(), ml.bit_length() - 1, nsel + W, inverse=False, coset_mont=off, in_len=n,
-                     stream=_stream(stream))
+        ntab = 4 if self.supports_lookup else 0
+        st = _stream(stream)
+        with _torch_on(st):
+            ev = torch.empty(nsel + W + ntab, ml * 4, dtype=torch.int64, device="cuda")
+            ev[:nsel, :n * 4].copy_(self.selectors)
+            ev[nsel:nsel + W, :n * 4].copy_(self.sigmas)
+            if ntab:
+                ev[nsel + W:, :n * 4].copy_(self.plookup_polys)
+            off = H.fr_to_mont(cp, [slice_offset(cp, m, rank)])[0]
+            L.ntt_device(self.curve, ev.data_ptr(), ml.bit_length() - 1, nsel + W + ntab, inverse=False, coset_mont=off,
+                         in_len=n, stream=st)
         self.coset_evals = ev
         self.coset_slice = (rank, world)
         return self
+
+
+@dataclass
+class PlookupEvaluations:
+    """plonk/src/proof_system/structs.rs:460-536"""
+    range_table_eval: int
+    key_table_eval: int
+    table_dom_sep_eval: int
+    q_dom_sep_eval: int
+    h_1_eval: int
+    q_lookup_eval: int
+    prod_next_eval: int
+    range_table_next_eval: int
+    key_table_next_eval: int
+    table_dom_sep_next_eval: int
+    h_1_next_eval: int
+    h_2_next_eval: int
+    q_lookup_next_eval: int
+    w_3_next_eval: int
+    w_4_next_eval: int
+
+    FIELDS = ("range_table_eval", "key_table_eval", "table_dom_sep_eval", "q_dom_sep_eval", "h_1_eval", "q_lookup_eval",
+              "prod_next_eval", "range_table_next_eval", "key_table_next_eval", "table_dom_sep_next_eval", "h_1_next_eval",
+              "h_2_next_eval", "q_lookup_next_eval", "w_3_next_eval", "w_4_next_eval")   # declaration = serialisation order
+
+    def evals_vec(self) -> list:
+        """the order at zeta in the transcript and the opening (structs.rs:511-520)"""
+        return [self.range_table_eval, self.key_table_eval, self.h_1_eval, self.q_lookup_eval, self.table_dom_sep_eval,
+                self.q_dom_sep_eval]
+
+    def next_evals_vec(self) -> list:
+        """the order at zeta * g (structs.rs:523-535)"""
+        return [self.prod_next_eval, self.range_table_next_eval, self.key_table_next_eval, self.h_1_next_eval,
+                self.h_2_next_eval, self.q_lookup_next_eval, self.w_3_next_eval, self.w_4_next_eval,
+                self.table_dom_sep_next_eval]
+
+    @classmethod
+    def from_vecs(cls, at_zeta, at_next) -> "PlookupEvaluations":
+        rt, kt, h1, ql, tds, qds = at_zeta
+        pn, rtn, ktn, h1n, h2n, qln, w3n, w4n, tdsn = at_next
+        return cls(rt, kt, tds, qds, h1, ql, pn, rtn, ktn, tdsn, h1n, h2n, qln, w3n, w4n)
+
+    def as_dict(self) -> dict:
+        return {k: getattr(self, k) for k in self.FIELDS}
+
+
+@dataclass
+class PlookupProof:
+    """plonk/src/proof_system/structs.rs:208-221"""
+    h_poly_comms: list
+    prod_lookup_poly_comm: tuple
+    poly_evals: PlookupEvaluations
+
+    def as_dict(self) -> dict:
+        return dict(h_poly_comms=self.h_poly_comms, prod_lookup_poly_comm=self.prod_lookup_poly_comm,
+                    poly_evals=self.poly_evals.as_dict())
+
+    def serialize_into(self, cp, out: bytearray):
+        out += len(self.h_poly_comms).to_bytes(8, "little")
+        for c in self.h_poly_comms:
+            out += H.ser_g1(cp, c)
+        out += H.ser_g1(cp, self.prod_lookup_poly_comm)
+        for k in PlookupEvaluations.FIELDS:
+            out += H.ser_fr(cp, getattr(self.poly_evals, k))
+
+
+def _ser_option_plookup(cp, out: bytearray, pp):
+    """ark-serialize Option<PlookupProof>: a flag byte, then the value"""
+    if pp is None:
+        out.append(0)
+    else:
+        out.append(1)
+        pp.serialize_into(cp, out)
 
 
 @dataclass
@@ -340,14 +517,18 @@ class Proof:
     wires_evals: list
     wire_sigma_evals: list
     perm_next_eval: int
+    plookup_proof: PlookupProof | None = None
 
     def as_dict(self) -> dict:
-        return {k: getattr(self, k) for k in ("wires_poly_comms", "prod_perm_poly_comm", "split_quot_poly_comms",
-                                              "opening_proof", "shifted_opening_proof", "wires_evals",
-                                              "wire_sigma_evals", "perm_next_eval")}
+        d = {k: getattr(self, k) for k in ("wires_poly_comms", "prod_perm_poly_comm", "split_quot_poly_comms",
+                                           "opening_proof", "shifted_opening_proof", "wires_evals",
+                                           "wire_sigma_evals", "perm_next_eval")}
+        if self.plookup_proof is not None:
+            d["plookup_proof"] = self.plookup_proof.as_dict()
+        return d
 
     def serialize_compressed(self) -> bytes:
-        """ark-serialize layout of `Proof` (plonk/src/proof_system/structs.rs:54-76); plookup_proof = None"""
+        """ark-serialize layout of `Proof` (plonk/src/proof_system/structs.rs:54-76)"""
         cp = H.CURVES[self.curve]
         out = bytearray()
         out += len(self.wires_poly_comms).to_bytes(8, "little")
@@ -363,7 +544,7 @@ class Proof:
             for x in v:
                 out += H.ser_fr(cp, x)
         out += H.ser_fr(cp, self.perm_next_eval)
-        out.append(0)
+        _ser_option_plookup(cp, out, self.plookup_proof)
         return bytes(out)
 
 
@@ -381,7 +562,7 @@ class ProofEvaluations:
 
 @dataclass
 class BatchProof:
-    """plonk/src/proof_system/structs.rs:227-249 (TurboPlonk instances: plookup_proofs_vec = [None; k])"""
+    """plonk/src/proof_system/structs.rs:227-249"""
     curve: int
     wires_poly_comms_vec: list
     prod_perm_poly_comms_vec: list
@@ -389,15 +570,19 @@ class BatchProof:
     split_quot_poly_comms: list
     opening_proof: tuple
     shifted_opening_proof: tuple
+    plookup_proofs_vec: list | None = None      # None = every instance is TurboPlonk ([None; k])
 
     def __len__(self) -> int:
         return len(self.prod_perm_poly_comms_vec)
 
     def as_dict(self) -> dict:
-        return dict(wires_poly_comms_vec=self.wires_poly_comms_vec, prod_perm_poly_comms_vec=self.prod_perm_poly_comms_vec,
-                    poly_evals_vec=[e.as_dict() for e in self.poly_evals_vec],
-                    split_quot_poly_comms=self.split_quot_poly_comms, opening_proof=self.opening_proof,
-                    shifted_opening_proof=self.shifted_opening_proof)
+        d = dict(wires_poly_comms_vec=self.wires_poly_comms_vec, prod_perm_poly_comms_vec=self.prod_perm_poly_comms_vec,
+                 poly_evals_vec=[e.as_dict() for e in self.poly_evals_vec],
+                 split_quot_poly_comms=self.split_quot_poly_comms, opening_proof=self.opening_proof,
+                 shifted_opening_proof=self.shifted_opening_proof)
+        if self.plookup_proofs_vec is not None and any(p is not None for p in self.plookup_proofs_vec):
+            d["plookup_proofs_vec"] = [None if p is None else p.as_dict() for p in self.plookup_proofs_vec]
+        return d
 
     def to_proof(self) -> "Proof":
         """the single-instance `Proof` (inverse of `impl From<Proof> for BatchProof`, structs.rs:275-287)"""
@@ -406,7 +591,8 @@ class BatchProof:
         e = self.poly_evals_vec[0]
         return Proof(self.curve, self.wires_poly_comms_vec[0], self.prod_perm_poly_comms_vec[0],
                      self.split_quot_poly_comms, self.opening_proof, self.shifted_opening_proof, e.wires_evals,
-                     e.wire_sigma_evals, e.perm_next_eval)
+                     e.wire_sigma_evals, e.perm_next_eval,
+                     self.plookup_proofs_vec[0] if self.plookup_proofs_vec is not None else None)
 
     def serialize_compressed(self) -> bytes:
         """ark-serialize layout of `BatchProof`"""
@@ -434,7 +620,8 @@ class BatchProof:
             vec_fr(e.wire_sigma_evals)
             out.extend(H.ser_fr(cp, e.perm_next_eval))
         out.extend(k.to_bytes(8, "little"))
-        out.extend(bytes(k))
+        for pp in self.plookup_proofs_vec if self.plookup_proofs_vec is not None else [None] * k:
+            _ser_option_plookup(cp, out, pp)
         vec_g1(self.split_quot_poly_comms)
         out.extend(H.ser_g1(cp, self.opening_proof))
         out.extend(H.ser_g1(cp, self.shifted_opening_proof))
@@ -493,6 +680,33 @@ def _stream(stream):
     if key not in _STREAMS:
         _STREAMS[key] = L.Stream(wrap_raw=raw)
     return _STREAMS[key]
+
+
+class _torch_on:
+    """run torch ops on the stream the library calls go to.  With the default argument (stream=None) that is torch's
+    current stream already; a caller-supplied jfhip stream (e.g. L.Stream(), a non-blocking HIP stream) is entered as a
+    torch ExternalStream, ordered after the work already queued on torch's current stream on entry and before what
+    follows on exit -- so torch copies / allocations and libjfhip kernels never run unordered."""
+
+    def __init__(self, st):
+        raw = st.raw
+        self.ext = None
+        if raw != torch.cuda.current_stream().cuda_stream:
+            self.ext = torch.cuda.ExternalStream(raw)
+
+    def __enter__(self):
+        if self.ext is not None:
+            self.outer = torch.cuda.current_stream()
+            self.ext.wait_stream(self.outer)
+            self.ctx = torch.cuda.stream(self.ext)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ext is not None:
+            self.ctx.__exit__(*exc)
+            self.outer.wait_stream(self.ext)
+        return False
 
 
 def _read_fr(cp, t: torch.Tensor) -> list[int]:
@@ -601,6 +815,63 @@ def unshard_quotient(cp, curve: int, gathered: torch.Tensor, m: int, out: torch.
                               stream=stream)
 
 
+def _sorted_lookup_vector(table: torch.Tensor, lookups: torch.Tensor) -> torch.Tensor:
+    """compute_lookup_sorted_vec_polynomials (relation/src/constraint_system.rs:1597-1620) before its two iffts, on
+    device rows of 4 x int64 (one field element each; equal elements have equal Montgomery limbs): every table element,
+    in table order, followed by as many copies as it is looked up -- counted at its FIRST occurrence in the table, as
+    the reference's HashMap entry is removed once used.  table: (n, 4), lookups: (n - 1, 4) -> (2n - 1, 4)."""
+    n = table.shape[0]
+    both = torch.cat([table, lookups])
+    _, inv = torch.unique(both, dim=0, return_inverse=True)
+    tid, lid = inv[:n], inv[n:]
+    nid = int(inv.max().item()) + 1
+    counts = torch.bincount(lid, minlength=nid)
+    pos = torch.arange(n, device=table.device)
+    first = torch.full((nid,), n, dtype=torch.int64, device=table.device).scatter_reduce(0, tid, pos, "amin")
+    in_table = first < n
+    if bool((counts[~in_table] != 0).any().item()):
+        raise PlonkError("The sorted vector has wrong length, some lookup variables might be outside the table")
+    mult = 1 + torch.where(first[tid] == pos, counts[tid], torch.zeros_like(tid))
+    out = torch.repeat_interleave(table, mult, dim=0)
+    if out.shape[0] != 2 * n - 1:
+        raise PlonkError("The sorted vector has wrong length, some lookup variables might be outside the table")
+    return out
+
+
+class _Placement:
+    """which rank proves which instance of a batch.  owners = None: every instance is on this GPU.  Otherwise
+    owners[i] is the rank (of `group`) that holds instance i's circuit and proving key; per-instance commitments and
+    evaluations travel as small python objects through all_gather_object, aggregated commitments as group sums of
+    un-normalised per-rank partial sums (one all_gather of 128 / 192 bytes per commitment)."""
+
+    def __init__(self, owners, group):
+        self.owners = owners
+        self.group = group
+        self.dist = owners is not None
+        if self.dist:
+            import torch.distributed as tdist
+
+            self.tdist = tdist
+            self.world = tdist.get_world_size(group)
+            self.me = tdist.get_rank(group)
+        else:
+            self.world, self.me = 1, 0
+
+    def local(self, i: int) -> bool:
+        return not self.dist or self.owners[i] == self.me
+
+    def gather(self, mine: dict, count: int) -> list:
+        """{instance: object} of this rank's instances -> the list over all instances"""
+        if not self.dist:
+            return [mine.get(i) for i in range(count)]
+        parts = [None] * self.world
+        self.tdist.all_gather_object(parts, mine, group=self.group)
+        merged = {}
+        for d in parts:
+            merged.update(d)
+        return [merged.get(i) for i in range(count)]
+
+
 class PlonkKzgSnark:
     @staticmethod
     def universal_setup_for_testing(curve: int, max_degree: int, beta: int, g=None, h=None) -> UniversalSrs:
@@ -615,44 +886,65 @@ class PlonkKzgSnark:
 
     @staticmethod
     def preprocess(srs: UniversalSrs, circuit: PlonkCircuit, stream=None):
-        """selector / sigma polynomials and their commitments (snark.rs:492-580), all on the device"""
+        """selector / sigma (/ Plookup table) polynomials and their commitments (snark.rs:492-580), all on the device"""
         cp = circuit.cp
         c = cp.curve_id
         n, log_n, W = circuit.eval_domain_size(), circuit.log_n, circuit.num_wire_types
         if srs.max_degree() < circuit.srs_size():
             raise PlonkError("IndexTooLarge")
+        ultra = circuit.support_lookup()
+        NSEL = N_TURBO_PLONK_SELECTORS + (1 if ultra else 0)
         st = _stream(stream)
-        # selector values -> coefficients (compute_selector_polynomials, constraint_system.rs:1359-1372)
-        table = np.stack([H.fr_to_mont(cp, k) for k in circuit.gate_kinds])             # (kinds, 13, 4)
-        sel_vals = np.ascontiguousarray(table[circuit.gate_kind].transpose(1, 0, 2))        # (13, n, 4)
-        selectors = _dev_fr(sel_vals).view(N_TURBO_PLONK_SELECTORS, n * 4)
-        L.ntt_device(c, selectors.data_ptr(), log_n, N_TURBO_PLONK_SELECTORS, inverse=True, stream=st)
-        # extended identity permutation id[i*n + j] = k_i g^j (constraint_system.rs:1116-1132): the forward NTT of k_i X
-        idp = torch.zeros(W, n * 4, dtype=torch.int64, device="cuda")
-        idp[:, 4:8] = _dev_fr(H.fr_to_mont(cp, circuit.k)).view(W, 4)
-        if n > 1:
-            L.ntt_device(c, idp.data_ptr(), log_n, W, inverse=False, stream=st)
-        # extended permutation (constraint_system.rs:1135-1161) and its polynomials (:1374-1392)
-        perm = torch.from_numpy(circuit.wire_permutation).cuda()
-        sigma_vals = idp.view(W * n, 4)[perm].contiguous().view(W, n * 4)
-        sigmas = sigma_vals.clone()
-        L.ntt_device(c, sigmas.data_ptr(), log_n, W, inverse=True, stream=st)
-        comms = _commit_many(srs.powers_of_g, cp, [selectors[j] for j in range(N_TURBO_PLONK_SELECTORS)]
-                             + [sigmas[j] for j in range(W)], [n] * (N_TURBO_PLONK_SELECTORS + W), st)
-        vk = VerifyingKey(n, circuit.num_inputs(), comms[N_TURBO_PLONK_SELECTORS:], comms[:N_TURBO_PLONK_SELECTORS],
-                          list(circuit.k), srs.g, srs.h, srs.beta_h)
-        pk = ProvingKey(c, sigmas, selectors, srs.powers_of_g, vk, idp, sigma_vals,
-                        torch.from_numpy(circuit.wire_variables.reshape(-1)).cuda())
-        pk.selector_is_zero = tuple(bool(z) for z in (~torch.any(selectors != 0, dim=1)).cpu().tolist())
+        with _torch_on(st):
+            # selector values -> coefficients (compute_selector_polynomials, constraint_system.rs:1359-1372)
+            table = np.stack([H.fr_to_mont(cp, k) for k in circuit.gate_kinds])             # (kinds, 13 or 17, 4)
+            by_gate = table[circuit.gate_kind]                                              # (n, 13 or 17, 4)
+            sel_vals = np.ascontiguousarray(by_gate[:, :NSEL].transpose(1, 0, 2))           # (NSEL, n, 4)
+            selectors = _dev_fr(sel_vals).view(NSEL, n * 4)
+            L.ntt_device(c, selectors.data_ptr(), log_n, NSEL, inverse=True, stream=st)
+            # extended identity permutation id[i*n + j] = k_i g^j (constraint_system.rs:1116-1132): the forward NTT of k_i X
+            idp = torch.zeros(W, n * 4, dtype=torch.int64, device="cuda")
+            idp[:, 4:8] = _dev_fr(H.fr_to_mont(cp, circuit.k)).view(W, 4)
+            if n > 1:
+                L.ntt_device(c, idp.data_ptr(), log_n, W, inverse=False, stream=st)
+            # extended permutation (constraint_system.rs:1135-1161) and its polynomials (:1374-1392)
+            perm = torch.from_numpy(circuit.wire_permutation).cuda()
+            sigma_vals = idp.view(W * n, 4)[perm].contiguous().view(W, n * 4)
+            sigmas = sigma_vals.clone()
+            L.ntt_device(c, sigmas.data_ptr(), log_n, W, inverse=True, stream=st)
+            polys = [selectors[j] for j in range(NSEL)] + [sigmas[j] for j in range(W)]
+            plookup_polys = table_vals = None
+            if ultra:
+                # compute_{range_table, key_table, table_dom_sep, q_dom_sep}_polynomial (constraint_system.rs:1460-1493)
+                if n < circuit.range_size():
+                    raise PlonkError("Domain size %d < range size %d" % (n, circuit.range_size()))
+                rng_tab = np.zeros((n, 4), dtype=np.uint64)
+                rng_tab[:circuit.range_size()] = H.fr_to_mont(cp, range(circuit.range_size()))
+                rows = [rng_tab, by_gate[:, _TABLE_KEY], by_gate[:, _TABLE_DOM_SEP], by_gate[:, _Q_DOM_SEP],
+                        by_gate[:, _Q_LOOKUP]]
+                table_vals = _dev_fr(np.ascontiguousarray(np.stack(rows))).view(5, n * 4)
+                plookup_polys = table_vals[:4].clone()
+                L.ntt_device(c, plookup_polys.data_ptr(), log_n, 4, inverse=True, stream=st)
+                polys += [plookup_polys[j] for j in range(4)]
+            comms = _commit_many(srs.powers_of_g, cp, polys, [n] * len(polys), st)
+            vk = VerifyingKey(n, circuit.num_inputs(), comms[NSEL:NSEL + W], comms[:NSEL], list(circuit.k), srs.g, srs.h,
+                              srs.beta_h)
+            if ultra:
+                pc = comms[NSEL + W:]
+                vk.plookup_vk = dict(range_table_comm=pc[0], key_table_comm=pc[1], table_dom_sep_comm=pc[2],
+                                     q_dom_sep_comm=pc[3])
+            pk = ProvingKey(c, sigmas, selectors, srs.powers_of_g, vk, idp, sigma_vals,
+                            torch.from_numpy(circuit.wire_variables.reshape(-1)).cuda(), plookup_polys, table_vals)
+            pk.selector_is_zero = tuple(bool(z) for z in (~torch.any(selectors != 0, dim=1)).cpu().tolist())
         return pk, vk
 
     @staticmethod
     def prove(rng, circuit: PlonkCircuit, prove_key: ProvingKey, extra_transcript_init_msg: bytes | None = None,
               stream=None, witness_mont: np.ndarray | None = None, sharded: bool = False, group=None) -> Proof:
-        """One TurboPlonk proof (snark.rs:587-613 -> batch_prove_internal :163-430 with one instance).
+        """One TurboPlonk / UltraPlonk proof (snark.rs:587-613 -> batch_prove_internal :163-430 with one instance).
         witness_mont: optional pre-converted witness table ((num_vars, 4) uint64 Montgomery), else converted here.
-        sharded: every rank of `group` calls prove with the same inputs (same RNG state); the 13 commitments' point
-        ranges are partitioned over the ranks (see _Committer); transforms and quotient run on every rank."""
+        sharded: every rank of `group` calls prove with the same inputs (same RNG state); the commitments' point
+        ranges are partitioned over the ranks (see _Committer) and the quotient coset is split into slices."""
         bp = PlonkKzgSnark._batch_prove_internal(rng, [circuit], [prove_key], extra_transcript_init_msg, stream,
                                                  None if witness_mont is None else [witness_mont], sharded, group)
         return bp.to_proof()
@@ -660,49 +952,130 @@ class PlonkKzgSnark:
     @staticmethod
     def batch_prove(rng, circuits, prove_keys, extra_transcript_init_msg: bytes | None = None, stream=None,
                     witness_monts=None, sharded: bool = False, group=None) -> "BatchProof":
-        """k TurboPlonk instances -> ONE aggregated BatchProof (snark.rs:61-74 -> :163-430): per round the instances
-        run in order on the one RNG and the one transcript, the quotient is sum_i alpha^(3i) t_i (prover.rs:519-656)
-        and the two opening proofs fold every instance's polynomials (prover.rs:356-413)."""
+        """k instances -> ONE aggregated BatchProof (snark.rs:61-74 -> :163-430): per round the instances run in order
+        on the one RNG and the one transcript, the quotient is sum_i alpha_base_i t_i (prover.rs:519-656) and the two
+        opening proofs fold every instance's polynomials (prover.rs:356-413)."""
         return PlonkKzgSnark._batch_prove_internal(rng, list(circuits), list(prove_keys), extra_transcript_init_msg,
                                                    stream, witness_monts, sharded, group)
 
     @staticmethod
+    def batch_prove_one_per_rank(rng, circuit: PlonkCircuit, prove_key: ProvingKey,
+                                 extra_transcript_init_msg: bytes | None = None, stream=None,
+                                 witness_mont: np.ndarray | None = None, group=None) -> "BatchProof":
+        """batch_prove with ONE circuit per GPU (BASELINE config 5's layout; SURVEY.md 8e): rank i of `group` holds
+        instance i (its circuit and proving key) and every rank returns the SAME BatchProof, byte-identical to
+        batch_prove(rng, [circuit_0 .. circuit_{G-1}], ...) on one GPU from the same RNG state.
+        * every rank runs the same transcript and the same RNG (it draws every instance's blinding in the reference's
+          order, snark.rs:245-318, prover.rs:926-940, and uses its own);
+        * per-instance commitments and evaluations are exchanged with one small all_gather per round;
+        * everything that mixes instances -- the quotient sum_i alpha_base_i t_i, its split, the linearisation and the
+          two opening polynomials (prover.rs:644-655, 356-413) -- is linear in the instances: each rank keeps its own
+          contribution, commits it without normalising (jfhip_msm_partial_device) and the aggregated commitment is
+          the group sum of the gathered partial sums.  No polynomial crosses xGMI."""
+        import torch.distributed as tdist
+
+        G = tdist.get_world_size(group)
+        me = tdist.get_rank(group)
+        circuits = [circuit if i == me else None for i in range(G)]
+        pks = [prove_key if i == me else None for i in range(G)]
+        wms = None if witness_mont is None else [witness_mont if i == me else None for i in range(G)]
+        return PlonkKzgSnark._batch_prove_internal(rng, circuits, pks, extra_transcript_init_msg, stream, wms, False,
+                                                   group, owners=list(range(G)))
+
+    @staticmethod
+    def batch_prove_placed(rng, circuits, prove_keys, owners, extra_transcript_init_msg: bytes | None = None, stream=None,
+                           witness_monts=None, group=None) -> "BatchProof":
+        """batch_prove with instance i proved on rank owners[i] (every rank owns at least one instance; entries of
+        circuits / prove_keys for instances of other ranks are ignored and may be None)"""
+        return PlonkKzgSnark._batch_prove_internal(rng, list(circuits), list(prove_keys), extra_transcript_init_msg,
+                                                   stream, witness_monts, False, group, owners=list(owners))
+
+    @staticmethod
     def _batch_prove_internal(rng, circuits, prove_keys, extra_transcript_init_msg, stream, witness_monts, sharded,
-                              group) -> "BatchProof":
+                              group, owners=None) -> "BatchProof":
         if not circuits:
             raise PlonkError("zero number of circuits/proving keys")
         if len(circuits) != len(prove_keys):
             raise PlonkError("the number of circuits %d != the number of proving keys %d"
                              % (len(circuits), len(prove_keys)))
+        if owners is not None and (sharded or len(owners) != len(circuits)):
+            raise PlonkError("instance placement needs one owner per instance and excludes point-range sharding")
+        st = _stream(stream)
+        with _torch_on(st):
+            return PlonkKzgSnark._prove_rounds(rng, circuits, prove_keys, extra_transcript_init_msg, st, witness_monts,
+                                               sharded, group, _Placement(owners, group))
+
+    @staticmethod
+    def _prove_rounds(rng, circuits, prove_keys, extra_transcript_init_msg, st, witness_monts, sharded, group,
+                      place) -> "BatchProof":
         K = len(circuits)
-        cp = circuits[0].cp
-        c, r = cp.curve_id, cp.r
-        n = circuits[0].eval_domain_size()
-        W = circuits[0].num_wire_types
-        for circuit, pk in zip(circuits, prove_keys):
+        mine = [i for i in range(K) if place.local(i)]
+        # ---- parameter checks (snark.rs:181-228) on this rank's instances, BEFORE any collective; with placement the
+        # verdicts travel with the verifying keys so that every rank raises the same error
+        err = None
+        cp = n = W = None
+        if not mine:
+            err = "rank %d owns no instance of the batch" % place.me
+        for i in mine:
+            circuit, pk = circuits[i], prove_keys[i]
+            if circuit is None or pk is None:
+                err = err or "instance %d is placed on this rank but has no circuit / proving key" % i
+                continue
+            if cp is None:
+                cp, n, W = circuit.cp, circuit.eval_domain_size(), circuit.num_wire_types
             if circuit.eval_domain_size() != n:
-                raise PlonkError("circuit domain size %d != expected domain size %d" % (circuit.eval_domain_size(), n))
+                err = err or "circuit domain size %d != expected domain size %d" % (circuit.eval_domain_size(), n)
             if pk.domain_size() != n:
-                raise PlonkError("proving key domain size %d != expected domain size %d" % (pk.domain_size(), n))
+                err = err or "proving key domain size %d != expected domain size %d" % (pk.domain_size(), n)
             if circuit.num_inputs() != pk.vk.num_inputs:
-                raise PlonkError("circuit.num_inputs %d != prove_key.num_inputs %d"
-                                 % (circuit.num_inputs(), pk.vk.num_inputs))
+                err = err or "circuit.num_inputs %d != prove_key.num_inputs %d" % (circuit.num_inputs(), pk.vk.num_inputs)
+            if circuit.support_lookup() != pk.supports_lookup:
+                err = err or "Mismatched Plonk types between the proving key and the circuit"
             if circuit.num_wire_types != W or circuit.cp is not cp:
+                err = err or "inconsistent plonk circuit types"
+            nv = witness_monts[i].shape[0] if witness_monts is not None and witness_monts[i] is not None \
+                else len(circuit.witness)
+            if nv != circuit.num_vars():
+                err = err or "witness table has %d rows, the circuit %d variables" % (nv, circuit.num_vars())
+        meta_mine = {}
+        if err is None:
+            meta_mine = {i: (prove_keys[i].vk, circuits[i].public_input(), circuits[i].support_lookup(), n, W,
+                             cp.curve_id) for i in mine}
+        if place.dist:
+            verdicts = [None] * place.world
+            place.tdist.all_gather_object(verdicts, err, group=place.group)
+            err = next((e for e in verdicts if e is not None), None)
+        if err is not None:
+            raise PlonkError(err)
+        meta = place.gather(meta_mine, K)
+        for (_, _, _, n_i, W_i, c_i) in meta:
+            if n_i != n:
+                raise PlonkError("circuit domain size %d != expected domain size %d" % (n_i, n))
+            if W_i != W or c_i != cp.curve_id:
                 raise PlonkError("inconsistent plonk circuit types")
-        log_n = circuits[0].log_n
+        vks = [x[0] for x in meta]
+        pub_inputs = [x[1] for x in meta]
+        lookup = [x[2] for x in meta]
+
+        c, r = cp.curve_id, cp.r
+        log_n = n.bit_length() - 1
         m = 1
         while m < n * domain_size_ratio(n, W):
             m <<= 1
         log_m = m.bit_length() - 1
         n4 = n * 4
-        ck = prove_keys[0].commit_key        # run_3rd_round / compute_opening_proofs use prove_keys[0].commit_key
-        st = _stream(stream)
-        commits = [_Committer(pk.commit_key, cp, st, sharded, group) for pk in prove_keys] if K > 1 else \
-            [_Committer(ck, cp, st, sharded, group)]
-        commit0 = commits[0]
+        first = mine[0]
+        ck = prove_keys[first].commit_key    # run_3rd_round / compute_opening_proofs use prove_keys[0].commit_key
+        commits = {i: _Committer(prove_keys[i].commit_key, cp, st, sharded, group) for i in mine}
+        commit0 = commits[first]
+        if place.dist:
+            from . import dist as jdist
+
+            engine = jdist.HipMsmEngine(L, ck, st)
         mont = lambda xs: H.fr_to_mont(cp, xs)  # noqa: E731
         gen = mont([cp.fr_generator])[0]
         group_gen = pow(cp.two_adic_root, 1 << (cp.two_adicity - log_n), r)
+        group_gen_inv = pow(group_gen, -1, r)
 
         import time as _time
 
@@ -715,12 +1088,12 @@ class PlonkKzgSnark:
                 PROFILE[name] = round(PROFILE.get(name, 0.0) + (now - t_last[0]) * 1e3, 3)
                 t_last[0] = now
 
-        pub_inputs = [circuit.public_input() for circuit in circuits]
+        def draw(count: int) -> list:
+            return [H.fr_rand(cp, rng) for _ in range(count)]
 
-        def mask(poly: torch.Tensor, hiding_bound: int):
+        def apply_mask(poly: torch.Tensor, b: list):
             """mask_polynomial (prover.rs:457-466): + (b_0 + .. + b_h X^h)(X^n - 1); poly has room for n + h + 1"""
-            b = [H.fr_rand(cp, rng) for _ in range(hiding_bound + 1)]
-            k = 4 * (hiding_bound + 1)
+            k = 4 * len(b)
             low = _read_fr(cp, poly[:k])
             poly[:k] = _dev_fr(mont([(x - y) % r for x, y in zip(low, b)]))
             poly[n4:n4 + k] = _dev_fr(mont(b))
@@ -740,19 +1113,39 @@ class PlonkKzgSnark:
                 acc = out
             return out
 
+        def commit_sum(polys, lens) -> list:
+            """commitments to the batch-wide polynomials (split quotient, opening polynomials).  One GPU: plain
+            commits.  With placement every rank holds its own share of each polynomial: un-normalised partial sums,
+            one all_gather, local fold (the polynomial is the sum of the shares and commit is linear)."""
+            if not place.dist:
+                return commit0(polys, lens)
+            for k in lens:
+                if k - 1 > len(ck) - 1:
+                    raise PlonkError("poly degree %d is larger than allowed %d" % (k - 1, len(ck) - 1))
+            parts = torch.cat([engine.partial(p[:4 * k]) for p, k in zip(polys, lens)])
+            st.sync()
+            allp = jdist._all_gather_bytes(parts, place.world, place.group).view(place.world, len(polys),
+                                                                                 engine.partial_bytes)
+            per = allp.transpose(0, 1).contiguous()
+            out = []
+            for j in range(len(polys)):
+                raw = engine.fold(per[j].reshape(-1), place.world).cpu().numpy().tobytes()
+                out.append(H.g1_from_record(cp, raw))
+            return out
+
         # ---- Round 1 (prover.rs:77-91): wire polynomials, public-input polynomial; instances in order
         ln = n + 3
         l4 = ln * 4
-        wire_vals_v, wire_polys_v, pub_poly_v, wires_poly_comms_vec, bufs = [], [], [], [], []
-        for i, (circuit, pk) in enumerate(zip(circuits, prove_keys)):
+        wire_vals_v, wire_polys_v, pub_poly_v, bufs = {}, {}, {}, {}
+        for i in mine:
+            circuit, pk = circuits[i], prove_keys[i]
             wm = witness_monts[i] if witness_monts is not None and witness_monts[i] is not None else mont(circuit.witness)
             wit = _dev_fr(wm).view(-1, 4)
-            if wit.shape[0] != circuit.num_vars():
-                raise PlonkError("witness table has %d rows, the circuit %d variables" % (wit.shape[0], circuit.num_vars()))
-            # witness[wire_variable(i, j)] for every (wire type, gate) (constraint_system.rs:1422-1444): one gather kernel
+            # witness[wire_variable(i, j)] for every (wire type, gate) (constraint_system.rs:1422-1444): one gather kernel;
+            # an index beyond the witness table (a proving key of another circuit) is an error, not a silent row 0
             wire_vals = torch.empty(W, n4, dtype=torch.int64, device="cuda")
             L.witness_gather_device(wit.data_ptr(), wit.shape[0], pk.wire_variables32.data_ptr(), W * n,
-                                    wire_vals.data_ptr(), stream=st)
+                                    wire_vals.data_ptr(), check=True, stream=st)
             buf = torch.empty(W + 1, n4, dtype=torch.int64, device="cuda")
             buf[:W].copy_(wire_vals)
             buf[W].zero_()
@@ -761,58 +1154,124 @@ class PlonkKzgSnark:
             # an empty public input is the zero polynomial: nothing to transform in row W
             L.ntt_device(c, buf.data_ptr(), log_n, W + (1 if pub_inputs[i] or not SKIP_ZERO_POLYS else 0), inverse=True,
                          stream=st)
-            wire_vals_v.append(wire_vals)
-            bufs.append(buf)
+            wire_vals_v[i] = wire_vals
+            bufs[i] = buf
         # the transcript is initialised (snark.rs:231-237) while the device runs the witness gather and the iNTTs
         tr = StandardTranscript(cp)
         if extra_transcript_init_msg is not None:
             tr.append_message(b"extra info", extra_transcript_init_msg)
-        for pk, pub_input in zip(prove_keys, pub_inputs):
-            tr.append_vk_and_pub_input(pk.vk, pub_input)
+        for vk, pub_input in zip(vks, pub_inputs):
+            tr.append_vk_and_pub_input(vk, pub_input)
         tick("r1_gather_intt_transcript_init")
-        for i, (circuit, pk) in enumerate(zip(circuits, prove_keys)):
+        comms_mine = {}
+        for i in range(K):
+            # RNG draws in the reference's order on every rank: b_0, b_1 of wire 0, then wire 1, ...
+            bs = [draw(2) for _ in range(W)]
+            if not place.local(i):
+                continue
             buf = bufs[i]
             wire_polys = torch.zeros(W, l4, dtype=torch.int64, device="cuda")
             wire_polys[:, :n4].copy_(buf[:W])
-            # mask_polynomial for the W wire polynomials with ONE read-back and two uploads (RNG draws in the
-            # reference's order: b_0, b_1 of wire 0, then wire 1, ...)
-            bs = [[H.fr_rand(cp, rng) for _ in range(2)] for _ in range(W)]
+            # mask_polynomial for the W wire polynomials with ONE read-back and two uploads
             low = _read_fr(cp, wire_polys[:, :8].contiguous().view(-1))
             wire_polys[:, :8] = _dev_fr(mont([(low[2 * j + t] - bs[j][t]) % r for j in range(W) for t in range(2)])).view(W, 8)
             wire_polys[:, n4:n4 + 8] = _dev_fr(mont([b for row in bs for b in row])).view(W, 8)
             tick("r1_mask")
-            comms = commits[i]([wire_polys[j] for j in range(W)], [n + 2] * W)
-            tr.append_commitments(b"witness_poly_comms", comms)
+            comms_mine[i] = commits[i]([wire_polys[j] for j in range(W)], [n + 2] * W)
             tick("r1_commit")
-            wire_polys_v.append(wire_polys)
-            pub_poly_v.append(buf[W])
-            wires_poly_comms_vec.append(comms)
+            wire_polys_v[i] = wire_polys
+            pub_poly_v[i] = buf[W]
         del bufs
+        wires_poly_comms_vec = place.gather(comms_mine, K)
+        for comms in wires_poly_comms_vec:
+            tr.append_commitments(b"witness_poly_comms", comms)
+
+        # ---- Round 1.5 (Plookup; snark.rs:254-284, prover.rs:99-124, constraint_system.rs:1495-1514, 1577-1624)
+        tau = tr.get_challenge(b"tau") if any(lookup) else None
+        h_polys_v, sorted_v, table_v, lkw_v, h_comms_mine = {}, {}, {}, {}, {}
+        for i in range(K):
+            if not lookup[i]:
+                continue
+            b1, b2 = draw(3), draw(3)
+            if not place.local(i):
+                continue
+            pk = prove_keys[i]
+            merged = torch.empty(2, n4, dtype=torch.int64, device="cuda")   # merged table, merged lookup witness
+            L.plonk_lookup_merge_device(c, log_n, wire_vals_v[i].data_ptr(), pk.plookup_table_vals.data_ptr(),
+                                        mont([tau])[0], merged[0].data_ptr(), merged[1].data_ptr(), stream=st)
+            # only the first n - 1 rows look up; the sorted concatenation has 2n - 1 entries
+            srt = _sorted_lookup_vector(merged[0].view(n, 4), merged[1].view(n, 4)[:n - 1]).reshape(-1)
+            h_polys = torch.zeros(2, l4, dtype=torch.int64, device="cuda")
+            h_polys[0, :n4].copy_(srt[:n4])
+            h_polys[1, :n4].copy_(srt[n4 - 4:])
+            hb = torch.empty(2, n4, dtype=torch.int64, device="cuda")
+            hb.copy_(h_polys[:, :n4])
+            L.ntt_device(c, hb.data_ptr(), log_n, 2, inverse=True, stream=st)
+            h_polys[:, :n4].copy_(hb)
+            apply_mask(h_polys[0], b1)
+            apply_mask(h_polys[1], b2)
+            tick("r1p_sorted_intt_mask")
+            h_comms_mine[i] = commits[i]([h_polys[0], h_polys[1]], [n + 3, n + 3])
+            tick("r1p_commit")
+            h_polys_v[i], sorted_v[i], table_v[i], lkw_v[i] = h_polys, srt, merged[0], merged[1]
+        h_comms_vec = place.gather(h_comms_mine, K) if any(lookup) else None
+        for i in range(K):
+            if lookup[i]:
+                tr.append_commitments(b"h_poly_comms", h_comms_vec[i])
 
         # ---- Round 2 (prover.rs:128-142; grand product constraint_system.rs:1394-1420)
         beta = tr.get_challenge(b"beta")
         gamma = tr.get_challenge(b"gamma")
         bg = mont([beta, gamma])
-        perm_poly_v, prod_perm_poly_comms_vec = [], []
-        for i, pk in enumerate(prove_keys):
+        perm_poly_v, perm_comms_mine = {}, {}
+        for i in range(K):
+            b = draw(3)
+            if not place.local(i):
+                continue
+            pk = prove_keys[i]
             perm_poly = torch.zeros(l4, dtype=torch.int64, device="cuda")
             L.plonk_perm_product_device(c, log_n, W, wire_vals_v[i].data_ptr(), pk.id_perm_vals.data_ptr(),
                                         pk.sigma_vals.data_ptr(), bg[0], bg[1], perm_poly.data_ptr(), stream=st)
             L.ntt_device(c, perm_poly.data_ptr(), log_n, 1, inverse=True, stream=st)
-            mask(perm_poly, 2)
+            apply_mask(perm_poly, b)
             tick("r2_product_intt_mask")
-            comm = commits[i]([perm_poly], [n + 3])[0]
-            tr.append_commitments(b"perm_poly_comms", [comm])
+            perm_comms_mine[i] = commits[i]([perm_poly], [n + 3])[0]
             tick("r2_commit")
-            perm_poly_v.append(perm_poly)
-            prod_perm_poly_comms_vec.append(comm)
+            perm_poly_v[i] = perm_poly
         del wire_vals_v
+        prod_perm_poly_comms_vec = place.gather(perm_comms_mine, K)
+        tr.append_commitments(b"perm_poly_comms", prod_perm_poly_comms_vec)
+
+        # ---- Round 2.5 (Plookup; snark.rs:298-318, prover.rs:147-178, constraint_system.rs:1516-1575)
+        pl_poly_v, pl_comms_mine = {}, {}
+        for i in range(K):
+            if not lookup[i]:
+                continue
+            b = draw(3)
+            if not place.local(i):
+                continue
+            pl_poly = torch.zeros(l4, dtype=torch.int64, device="cuda")
+            L.plonk_lookup_product_device(c, log_n, lkw_v[i].data_ptr(), table_v[i].data_ptr(), sorted_v[i].data_ptr(),
+                                          bg[0], bg[1], pl_poly.data_ptr(), stream=st)
+            L.ntt_device(c, pl_poly.data_ptr(), log_n, 1, inverse=True, stream=st)
+            apply_mask(pl_poly, b)
+            tick("r2p_product_intt_mask")
+            pl_comms_mine[i] = commits[i]([pl_poly], [n + 3])[0]
+            tick("r2p_commit")
+            pl_poly_v[i] = pl_poly
+        del sorted_v, table_v, lkw_v
+        pl_comms_vec = place.gather(pl_comms_mine, K) if any(lookup) else None
+        for i in range(K):
+            if lookup[i]:
+                tr.append_commitments(b"plookup_poly_comms", [pl_comms_vec[i]])
 
         # ---- Round 3 (prover.rs:183-198, 491-661, 894-943)
         alpha = tr.get_challenge(b"alpha")
-        alpha_3 = pow(alpha, 3, r)
-        alpha_bases = [pow(alpha_3, i, r) for i in range(K)]
-        NSEL = N_TURBO_PLONK_SELECTORS
+        alpha_3, alpha_7 = pow(alpha, 3, r), pow(alpha, 7, r)
+        alpha_bases, ab = [], 1
+        for i in range(K):
+            alpha_bases.append(ab)
+            ab = ab * (alpha_7 if lookup[i] else alpha_3) % r      # prover.rs:651-655
         # coset sharding: rank g of G evaluates the slice i = g (mod G) of the quotient coset, a coset of
         # size ml = m / G with offset h w_m^g; one all_gather of the slices' iNTTs rebuilds the quotient polynomial
         G, g = 1, 0
@@ -830,18 +1289,20 @@ class PlonkKzgSnark:
         lc4 = min(l4, ml * 4)
         quot = torch.zeros(m * 4, dtype=torch.int64, device="cuda")
         part = torch.zeros(ml * 4, dtype=torch.int64, device="cuda") if G > 1 else None
-        for i, pk in enumerate(prove_keys):
-            vk, wire_polys, perm_poly = pk.vk, wire_polys_v[i], perm_poly_v[i]
+        for i in mine:
+            pk, vk, wire_polys, perm_poly = prove_keys[i], vks[i], wire_polys_v[i], perm_poly_v[i]
+            NSEL = pk.selectors.shape[0]
+            nlk = 7 if lookup[i] else 0
             if pk.coset_evals is not None:
-                # selector / sigma coset evaluations are resident with the proving key: 7 transforms instead of 25
+                # selector / sigma (/ table) coset evaluations are resident with the proving key
                 fixed = pk.coset_evals
-                if fixed.shape != (NSEL + W, ml * 4) or pk.coset_slice != (g, G):
+                if fixed.shape != (NSEL + W + (4 if lookup[i] else 0), ml * 4) or pk.coset_slice != (g, G):
                     raise PlonkError("proving key coset evaluations were kept for another slice of the quotient coset")
-                npolys, o_w = W + 2, 0
+                npolys, o_w = W + 2 + nlk, 0
                 sel_ptr, sig_ptr = fixed[0].data_ptr(), fixed[NSEL].data_ptr()
             else:
-                npolys, o_w = NSEL + 2 * W + 2, NSEL + W
-            o_z, o_pi = o_w + W, o_w + W + 1
+                npolys, o_w = NSEL + 2 * W + 2 + nlk, NSEL + W
+            o_z, o_pi, o_lk = o_w + W, o_w + W + 1, o_w + W + 2
             cs = torch.empty(npolys, ml * 4, dtype=torch.int64, device="cuda")
             cs[:, n4:lc4].zero_()
             if pk.coset_evals is None:
@@ -851,27 +1312,43 @@ class PlonkKzgSnark:
             cs[o_w:o_z, :lc4].copy_(wire_polys[:, :lc4])
             cs[o_z, :lc4].copy_(perm_poly[:lc4])
             cs[o_pi, :n4].copy_(pub_poly_v[i])
+            online = [wire_polys[j] for j in range(W)] + [perm_poly]      # polynomials of n + 2 / n + 3 coefficients
+            online_rows = list(range(o_w, o_z + 1))
+            if lookup[i]:
+                # the quotient kernel's Plookup rows: range_table, key_table, table_dom_sep, q_dom_sep, h_1, h_2, prod_lookup
+                if pk.coset_evals is None:
+                    cs[o_lk:o_lk + 4, :n4].copy_(pk.plookup_polys)
+                cs[o_lk + 4:o_lk + 6, :lc4].copy_(h_polys_v[i][:, :lc4])
+                cs[o_lk + 6, :lc4].copy_(pl_poly_v[i][:lc4])
+                online += [h_polys_v[i][0], h_polys_v[i][1], pl_poly_v[i]]
+                online_rows += [o_lk + 4, o_lk + 5, o_lk + 6]
             if lc4 < l4:
                 # ml = n < n + 3 coefficients: reduce mod X^ml - off^ml (the slice's vanishing polynomial)
                 fold = mont([1, pow(off_int, ml, r)])
                 k = (l4 - lc4) // 4
-                tmp = torch.empty(W + 1, k * 4, dtype=torch.int64, device="cuda")
-                for j, poly in enumerate([wire_polys[j] for j in range(W)] + [perm_poly]):
+                tmp = torch.empty(len(online), k * 4, dtype=torch.int64, device="cuda")
+                for j, poly in enumerate(online):
                     L.poly_lincomb_device(c, [poly.data_ptr(), poly.data_ptr() + lc4 * 8], [k, k], fold,
                                           tmp[j].data_ptr(), k, stream=st)
-                cs[o_w:o_z + 1, :k * 4].copy_(tmp)
+                for j, row in enumerate(online_rows):
+                    cs[row, :k * 4].copy_(tmp[j])
             # identically-zero polynomials: no transform, and the quotient kernel is told not to read their rows
             zmask = sum(1 << j for j, z in enumerate(pk.selector_is_zero) if z) if SKIP_ZERO_POLYS else 0
             pi_zero = SKIP_ZERO_POLYS and not pub_inputs[i]
             zero_rows = [o_pi] if pi_zero else []
             if pk.coset_evals is None:
                 zero_rows += [j for j in range(NSEL) if (zmask >> j) & 1]
+            elif lookup[i]:
+                zero_rows += list(range(o_lk, o_lk + 4))          # resident: copied below, not transformed
             _coset_ntt_rows(c, cs, zero_rows, log_ml, off, lc4 // 4, st)
+            if pk.coset_evals is not None and lookup[i]:
+                cs[o_lk:o_lk + 4].copy_(pk.coset_evals[NSEL + W:])
             tick("r3_coset_ntts")
-            chal = mont([alpha, beta, gamma, alpha_bases[i]])
+            chal = mont([alpha, beta, gamma] + ([tau] if lookup[i] else []) + [alpha_bases[i]])
             # G == 1: the slice is the whole quotient coset (offset Fr::GENERATOR, log_ml = log_m)
             L.plonk_quotient_masked_device(c, W, log_n, log_ml, off, sel_ptr, sig_ptr, cs[o_w].data_ptr(),
-                                           cs[o_z].data_ptr(), 0 if pi_zero else cs[o_pi].data_ptr(), 0, mont(vk.k), chal,
+                                           cs[o_z].data_ptr(), 0 if pi_zero else cs[o_pi].data_ptr(),
+                                           cs[o_lk].data_ptr() if lookup[i] else 0, mont(vk.k), chal,
                                            zmask, (quot if G == 1 else part).data_ptr(), stream=st)
             del cs                             # stream-ordered: the next allocation is used on the same stream
             tick("r3_quotient_intt")
@@ -894,74 +1371,114 @@ class PlonkKzgSnark:
         expected_degree = W * (n + 1) + 2
         # the split randomisers (prover.rs:926-940) are drawn while the device still works on the quotient: the next RNG
         # draws in the reference's order whether or not the degree check below passes
-        randomizers = [H.fr_rand(cp, rng) for _ in range(W - 1)]
-        randomizers_dev = _dev_fr(mont(randomizers)).view(W - 1, 4)
+        randomizers = draw(W - 1)
+        owns_first = place.local(0)           # the blinding of the split goes on the share that holds instance 0
         split = torch.zeros(W, l4, dtype=torch.int64, device="cuda")
         step = (n + 2) * 4
         for i in range(W - 1):
             split[i, :step].copy_(quot[i * step:(i + 1) * step])
         last_len = expected_degree + 1 - (W - 1) * (n + 2)
         split[W - 1, :last_len * 4].copy_(quot[(W - 1) * step:(expected_degree + 1) * 4])
-        split[:W - 1, step:step + 4] = randomizers_dev
+        if owns_first:
+            split[:W - 1, step:step + 4] = _dev_fr(mont(randomizers)).view(W - 1, 4)
         # ONE read-back: [tail non-zero flag, top coefficient, first coefficient of every piece]
         flag = torch.any(quot[(expected_degree + 1) * 4:] != 0).to(torch.int64).view(1)
         back = torch.cat([flag, quot[expected_degree * 4:(expected_degree + 1) * 4],
                           split[:, :4].contiguous().view(-1)]).cpu().numpy()
         del quot
-        if back[0] != 0 or not back[1:5].any():
+        # degree check on the whole quotient = the sum of the ranks' shares (prover.rs:900-903)
+        if place.dist:
+            per_rank = [None] * place.world
+            place.tdist.all_gather_object(per_rank, (int(back[0]), H.fr_from_mont(cp, back[1:5].view(np.uint64))[0]),
+                                          group=place.group)
+            tail_bad, top = any(t for t, _ in per_rank), sum(x for _, x in per_rank) % r
+        else:
+            tail_bad, top = bool(back[0]), int(back[1:5].any())
+        if tail_bad or not top:
             raise PlonkError("WrongQuotientPolyDegree(expected %d)" % expected_degree)
-        firsts = H.fr_from_mont(cp, back[5:].view(np.uint64))
-        last_randomizer = 0
-        for i in range(W - 1):
-            firsts[i] = (firsts[i] - last_randomizer) % r
-            last_randomizer = randomizers[i]
-        firsts[W - 1] = (firsts[W - 1] - last_randomizer) % r
-        split[:, :4] = _dev_fr(mont(firsts)).view(W, 4)
+        if owns_first:
+            firsts = H.fr_from_mont(cp, back[5:].view(np.uint64))
+            last_randomizer = 0
+            for i in range(W - 1):
+                firsts[i] = (firsts[i] - last_randomizer) % r
+                last_randomizer = randomizers[i]
+            firsts[W - 1] = (firsts[W - 1] - last_randomizer) % r
+            split[:, :4] = _dev_fr(mont(firsts)).view(W, 4)
         split_lens = [n + 3] * (W - 1) + [last_len]
         tick("r3_split_mask")
-        split_quot_poly_comms = commit0([split[j] for j in range(W)], split_lens)
+        split_quot_poly_comms = commit_sum([split[j] for j in range(W)], split_lens)
         tr.append_commitments(b"quot_poly_comms", split_quot_poly_comms)
         tick("r3_commit")
 
-        # ---- Round 4 (prover.rs:205-229): evaluations, instances in order
+        # ---- Round 4 / 4.5 (prover.rs:205-296): evaluations at zeta and zeta * g, instances in order
         zeta = tr.get_challenge(b"zeta")
         zeta_omega = zeta * group_gen % r
         zm, zom = mont([zeta])[0], mont([zeta_omega])[0]
-        evals_dev = torch.zeros(K * (2 * W) * 4, dtype=torch.int64, device="cuda")
-        at_zeta_v = []
-        for i, pk in enumerate(prove_keys):
+        at_zeta_v, at_next_v, evals_mine = {}, {}, {}
+        pending = []
+        for i in mine:
+            pk = prove_keys[i]
             at_zeta = [(wire_polys_v[i][j], n + 2) for j in range(W)] + [(pk.sigmas[j], n) for j in range(W - 1)]
-            base = evals_dev.data_ptr() + i * 2 * W * 32
-            L.poly_eval_batch_device(c, [p.data_ptr() for p, _ in at_zeta], [k for _, k in at_zeta], zm, base, stream=st)
-            L.poly_eval_batch_device(c, [perm_poly_v[i].data_ptr()], [n + 3], zom, base + (2 * W - 1) * 32, stream=st)
-            at_zeta_v.append(at_zeta)
-        ev_all = _read_fr(cp, evals_dev)
-        poly_evals_vec = []
+            at_next = [(perm_poly_v[i], n + 3)]
+            if lookup[i]:
+                rt, kt, tds, qds = (pk.plookup_polys[j] for j in range(4))
+                ql = pk.selectors[pk.selectors.shape[0] - 1]
+                h1, h2 = h_polys_v[i][0], h_polys_v[i][1]
+                # plookup_open_polys_ref / plookup_shifted_open_polys_ref (prover.rs:421-453)
+                at_zeta += [(rt, n), (kt, n), (h1, n + 3), (ql, n), (tds, n), (qds, n)]
+                at_next += [(pl_poly_v[i], n + 3), (rt, n), (kt, n), (h1, n + 3), (h2, n + 3), (ql, n),
+                            (wire_polys_v[i][3], n + 2), (wire_polys_v[i][4], n + 2), (tds, n)]
+            ev = torch.zeros((len(at_zeta) + len(at_next)) * 4, dtype=torch.int64, device="cuda")
+            L.poly_eval_batch_device(c, [p.data_ptr() for p, _ in at_zeta], [k for _, k in at_zeta], zm, ev.data_ptr(),
+                                     stream=st)
+            L.poly_eval_batch_device(c, [p.data_ptr() for p, _ in at_next], [k for _, k in at_next], zom,
+                                     ev.data_ptr() + len(at_zeta) * 32, stream=st)
+            at_zeta_v[i], at_next_v[i] = at_zeta, at_next
+            pending.append((i, ev))
+        if pending:
+            flat = _read_fr(cp, torch.cat([ev for _, ev in pending]))
+            at = 0
+            for i, ev in pending:
+                cnt = ev.numel() // 4
+                evals_mine[i] = flat[at:at + cnt]
+                at += cnt
+        evals_all = place.gather(evals_mine, K)
+        poly_evals_vec, plookup_evals_vec = [], []
         for i in range(K):
-            ev = ev_all[i * 2 * W:(i + 1) * 2 * W]
-            pe = ProofEvaluations(ev[:W], ev[W:2 * W - 1], ev[2 * W - 1])
+            ev = evals_all[i]
+            nz = 2 * W - 1 + (6 if lookup[i] else 0)
+            pe = ProofEvaluations(ev[:W], ev[W:2 * W - 1], ev[nz])
+            poly_evals_vec.append(pe)
+            plookup_evals_vec.append(PlookupEvaluations.from_vecs(ev[2 * W - 1:nz], ev[nz + 1:nz + 10]) if lookup[i]
+                                     else None)
+        for pe in poly_evals_vec:
             tr.append_field_elems(b"wire_evals", pe.wires_evals)
             tr.append_field_elems(b"wire_sigma_evals", pe.wire_sigma_evals)
             tr.append_field_elems(b"perm_next_eval", [pe.perm_next_eval])
-            poly_evals_vec.append(pe)
+        for ple in plookup_evals_vec:
+            if ple is not None:      # transcript/mod.rs:155-162
+                tr.append_field_elems(b"plookup_evals", ple.evals_vec())
+                tr.append_field_elems(b"plookup_next_evals", ple.next_evals_vec())
         tick("r4_evals")
 
-        # linearisation polynomial (snark.rs:364-389; prover.rs:299-352, 946-1015) as device linear combinations
+        # linearisation polynomial (snark.rs:364-389; prover.rs:299-352, 946-1087) as device linear combinations: the
+        # quotient part over this rank's split share + the part of each of its instances
         vanish_eval = (pow(zeta, n, r) - 1) % r
         zeta_to_n_plus_2 = (vanish_eval + 1) * zeta % r * zeta % r
         lagrange_1_eval = vanish_eval * pow(n * (zeta - 1) % r, -1, r) % r
+        lagrange_n_eval = vanish_eval * group_gen_inv % r * pow(n * (zeta - group_gen_inv) % r, -1, r) % r
         terms = []
         coeff = 1
         for i in range(W):
             if i:
                 coeff = coeff * zeta_to_n_plus_2 % r
             terms.append((-vanish_eval * coeff % r, split[i], split_lens[i]))
-        for i, pk in enumerate(prove_keys):
-            ab, vk, pe = alpha_bases[i], pk.vk, poly_evals_vec[i]
+        for i in mine:
+            pk, vk, pe, ab = prove_keys[i], vks[i], poly_evals_vec[i], alpha_bases[i]
             w = pe.wires_evals
             q_scalars = [w[0], w[1], w[2], w[3], w[0] * w[1], w[2] * w[3], pow(w[0], 5, r), pow(w[1], 5, r),
                          pow(w[2], 5, r), pow(w[3], 5, r), -w[4], 1, w[0] * w[1] * w[2] * w[3] * w[4]]
-            terms += [(s % r * ab % r, pk.selectors[j], n) for j, s in enumerate(q_scalars)]
+            terms += [(s % r * ab % r, pk.selectors[j], n) for j, s in enumerate(q_scalars)]   # q_lookup is not in r_circ
             cz = alpha
             for j in range(W):
                 cz = cz * (w[j] + beta * vk.k[j] % r * zeta + gamma) % r
@@ -971,287 +1488,65 @@ class PlonkKzgSnark:
             for j in range(W - 1):
                 csig = csig * (w[j] + beta * pe.wire_sigma_evals[j] + gamma) % r
             terms.append((-csig * ab % r, pk.sigmas[W - 1], n))
+            if lookup[i]:
+                # compute_lin_poly_plookup_contribution (prover.rs:1017-1087)
+                le = plookup_evals_vec[i]
+                a4, a5, a6 = pow(alpha, 4, r), pow(alpha, 5, r), pow(alpha, 6, r)
+
+                def merged_table(rg, ky, ql, w3, w4, td):          # eval_merged_table, structs.rs:899-914
+                    return (rg + ql * tau % r * (td + tau * (ky + tau * (w3 + tau * w4)))) % r
+
+                mt = merged_table(le.range_table_eval, le.key_table_eval, le.q_lookup_eval, w[3], w[4],
+                                  le.table_dom_sep_eval)
+                mt_next = merged_table(le.range_table_next_eval, le.key_table_next_eval, le.q_lookup_next_eval,
+                                       le.w_3_next_eval, le.w_4_next_eval, le.table_dom_sep_next_eval)
+                # eval_merged_lookup_witness, structs.rs:916-931
+                ml_ev = (w[5] + le.q_lookup_eval * tau % r * (le.q_dom_sep_eval + tau * (w[0] + tau * (w[1] + tau * w[2])))) % r
+                b1 = (1 + beta) % r
+                zmg = (zeta - group_gen_inv) % r
+                c_p = (a4 * lagrange_1_eval + a5 * lagrange_n_eval
+                       + a6 * zmg % r * b1 % r * (gamma + ml_ev) % r * (gamma * b1 + mt + beta * mt_next)) % r
+                terms.append((c_p * ab % r, pl_poly_v[i], n + 3))
+                c_h2 = -a6 * zmg % r * le.prod_next_eval % r * (gamma * b1 + le.h_1_eval + beta * le.h_1_next_eval) % r
+                terms.append((c_h2 * ab % r, h_polys_v[i][1], n + 3))
         lin_poly = lincomb(terms, n + 3)
         tick("r4_lin_poly")
 
-        # ---- Round 5 (prover.rs:356-413, 470-488): batched opening quotients over every instance
+        # ---- Round 5 (prover.rs:356-413, 470-488): batched opening quotients over every instance; division by
+        # (X - z) is linear, so with placement each rank divides and commits its own share
         v = tr.get_challenge(b"v")
-        polys = [(lin_poly, n + 3)]
-        for at_zeta in at_zeta_v:
-            polys += at_zeta
-        open_terms, cur = [], 1
-        for p, k in polys:
-            open_terms.append((cur, p, k))
-            cur = cur * v % r
+        open_terms = [(1, lin_poly, n + 3)]
+        sh_terms = []
+        pos_z, pos_n = 1, 0                     # exponent of v of the next polynomial at zeta / at zeta * g
+        for i in range(K):
+            cnt_z = 2 * W - 1 + (6 if lookup[i] else 0)
+            cnt_n = 1 + (9 if lookup[i] else 0)
+            if place.local(i):
+                cur = pow(v, pos_z, r)
+                for p, k in at_zeta_v[i]:
+                    open_terms.append((cur, p, k))
+                    cur = cur * v % r
+                cur = pow(v, pos_n, r)
+                for p, k in at_next_v[i]:
+                    sh_terms.append((cur, p, k))
+                    cur = cur * v % r
+            pos_z += cnt_z
+            pos_n += cnt_n
         open_poly = lincomb(open_terms, n + 3)
-        if K == 1:
+        if not place.dist and K == 1 and not lookup[0]:
             shifted_poly = perm_poly_v[0]
         else:
-            sh_terms, cur = [], 1
-            for z in perm_poly_v:
-                sh_terms.append((cur, z, n + 3))
-                cur = cur * v % r
             shifted_poly = lincomb(sh_terms, n + 3)
         wpoly = torch.zeros(2, l4, dtype=torch.int64, device="cuda")
         L.poly_divide_linear_device(c, open_poly.data_ptr(), n + 3, zm, wpoly[0].data_ptr(), stream=st)
         L.poly_divide_linear_device(c, shifted_poly.data_ptr(), n + 3, zom, wpoly[1].data_ptr(), stream=st)
         tick("r5_open_polys")
-        opening_proof, shifted_opening_proof = commit0([wpoly[0][4:], wpoly[1][4:]], [n + 2, n + 2])
+        opening_proof, shifted_opening_proof = commit_sum([wpoly[0][4:], wpoly[1][4:]], [n + 2, n + 2])
         tick("r5_commit")
 
+        plookup_proofs_vec = None
+        if any(lookup):
+            plookup_proofs_vec = [PlookupProof(h_comms_vec[i], pl_comms_vec[i], plookup_evals_vec[i]) if lookup[i] else None
+                                  for i in range(K)]
         return BatchProof(c, wires_poly_comms_vec, prod_perm_poly_comms_vec, poly_evals_vec, split_quot_poly_comms,
-                          opening_proof, shifted_opening_proof)
-
-    @staticmethod
-    def batch_prove_one_per_rank(rng, circuit: PlonkCircuit, prove_key: ProvingKey,
-                                 extra_transcript_init_msg: bytes | None = None, stream=None,
-                                 witness_mont: np.ndarray | None = None, group=None) -> "BatchProof":
-        """batch_prove with ONE circuit per GPU (BASELINE config 5's layout; SURVEY.md 8e): rank i of `group` holds
-        instance i (its circuit and proving key) and every rank returns the SAME BatchProof, byte-identical to
-        batch_prove(rng, [circuit_0 .. circuit_{G-1}], ...) on one GPU from the same RNG state.
-        * every rank runs the same transcript and the same RNG (it draws every instance's blinding in the reference's
-          order, snark.rs:245-318, prover.rs:926-940, and uses its own);
-        * per-instance commitments and evaluations are exchanged with one small all_gather per round;
-        * everything that mixes instances -- the quotient sum_i alpha^(3i) t_i, its split, the linearisation and the
-          two opening polynomials (prover.rs:644-655, 356-413) -- is linear in the instances: each rank keeps its own
-          contribution, commits it without normalising (jfhip_msm_partial_device) and the aggregated commitment is
-          the group sum of the gathered partial sums.  No polynomial crosses xGMI."""
-        import torch.distributed as tdist
-
-        from . import dist as jdist
-
-        G = tdist.get_world_size(group)
-        me = tdist.get_rank(group)
-        cp = circuit.cp
-        c, r = cp.curve_id, cp.r
-        pk, vk = prove_key, prove_key.vk
-        n, log_n, W = circuit.eval_domain_size(), circuit.log_n, circuit.num_wire_types
-        if pk.domain_size() != n:
-            raise PlonkError("proving key domain size %d != expected domain size %d" % (pk.domain_size(), n))
-        if circuit.num_inputs() != vk.num_inputs:
-            raise PlonkError("circuit.num_inputs %d != prove_key.num_inputs %d" % (circuit.num_inputs(), vk.num_inputs))
-        m = 1
-        while m < n * domain_size_ratio(n, W):
-            m <<= 1
-        log_m = m.bit_length() - 1
-        n4, ln = n * 4, n + 3
-        l4 = ln * 4
-        st = _stream(stream)
-        commit = _Committer(pk.commit_key, cp, st)
-        engine = jdist.HipMsmEngine(L, pk.commit_key, st)
-        mont = lambda xs: H.fr_to_mont(cp, xs)  # noqa: E731
-        gen = mont([cp.fr_generator])[0]
-        group_gen = pow(cp.two_adic_root, 1 << (cp.two_adicity - log_n), r)
-        rec = 16 * cp.fq_limbs64 + 4
-
-        def gather_points(points) -> list:
-            """[rank][j] of every rank's affine points (packed records through one all_gather)"""
-            raw = bytearray()
-            for P in points:
-                raw += H.g1_to_record(cp, P)
-            mine = torch.frombuffer(raw, dtype=torch.uint8).cuda()
-            out = jdist._all_gather_bytes(mine, G, group).cpu().numpy().tobytes()
-            k = len(points)
-            return [[H.g1_from_record(cp, out[(q * k + j) * rec:(q * k + j + 1) * rec]) for j in range(k)]
-                    for q in range(G)]
-
-        def gather_ints(xs) -> list:
-            raw = b"".join(int(x).to_bytes(32, "little") for x in xs)
-            mine = torch.frombuffer(bytearray(raw), dtype=torch.uint8).cuda()
-            out = jdist._all_gather_bytes(mine, G, group).cpu().numpy().tobytes()
-            k = len(xs)
-            return [[int.from_bytes(out[(q * k + j) * 32:(q * k + j + 1) * 32], "little") for j in range(k)]
-                    for q in range(G)]
-
-        def aggregated_commit(polys, lens) -> list:
-            """sum over ranks of commit(rank's polynomial): un-normalised partial sums, one all_gather, local fold"""
-            for k in lens:
-                if k - 1 > len(pk.commit_key) - 1:
-                    raise PlonkError("poly degree %d is larger than allowed %d" % (k - 1, len(pk.commit_key) - 1))
-            parts = torch.cat([engine.partial(p[:4 * k]) for p, k in zip(polys, lens)])
-            st.sync()
-            allp = jdist._all_gather_bytes(parts, G, group).view(G, len(polys), engine.partial_bytes)
-            per = allp.transpose(0, 1).contiguous()
-            out = []
-            for j in range(len(polys)):
-                raw = engine.fold(per[j].reshape(-1), G).cpu().numpy().tobytes()
-                out.append(H.g1_from_record(cp, raw))
-            return out
-
-        def lincomb(terms, out_len: int) -> torch.Tensor:
-            out = torch.zeros(out_len * 4, dtype=torch.int64, device="cuda")
-            L.poly_lincomb_device(c, [p.data_ptr() for _, p, _ in terms], [k for _, _, k in terms],
-                                  mont([s % r for s, _, _ in terms]), out.data_ptr(), out_len, stream=st)
-            return out
-
-        # every rank needs every instance's verifying key and public input for the shared transcript
-        pub_input = circuit.public_input()
-        everyone = [None] * G
-        tdist.all_gather_object(everyone, (vk, pub_input), group=group)
-        for other_vk, _ in everyone:
-            if other_vk.domain_size != n:
-                raise PlonkError("circuit domain size %d != expected domain size %d" % (other_vk.domain_size, n))
-        tr = StandardTranscript(cp)
-        if extra_transcript_init_msg is not None:
-            tr.append_message(b"extra info", extra_transcript_init_msg)
-        for other_vk, other_pub in everyone:
-            tr.append_vk_and_pub_input(other_vk, other_pub)
-
-        # ---- Round 1: the RNG draws of all instances in order, this rank keeps its own
-        bs = [[[H.fr_rand(cp, rng) for _ in range(2)] for _ in range(W)] for _ in range(G)][me]
-        wit = _dev_fr(witness_mont if witness_mont is not None else mont(circuit.witness)).view(-1, 4)
-        if wit.shape[0] != circuit.num_vars():
-            raise PlonkError("witness table has %d rows, the circuit %d variables" % (wit.shape[0], circuit.num_vars()))
-        wire_vals = torch.empty(W, n4, dtype=torch.int64, device="cuda")
-        L.witness_gather_device(wit.data_ptr(), wit.shape[0], pk.wire_variables32.data_ptr(), W * n, wire_vals.data_ptr(),
-                                stream=st)
-        buf = torch.empty(W + 1, n4, dtype=torch.int64, device="cuda")
-        buf[:W].copy_(wire_vals)
-        buf[W].zero_()
-        if pub_input:
-            buf[W, :4 * len(pub_input)] = _dev_fr(mont(pub_input))
-        L.ntt_device(c, buf.data_ptr(), log_n, W + 1, inverse=True, stream=st)
-        wire_polys = torch.zeros(W, l4, dtype=torch.int64, device="cuda")
-        wire_polys[:, :n4].copy_(buf[:W])
-        pub_poly = buf[W]
-        low = _read_fr(cp, wire_polys[:, :8].contiguous().view(-1))
-        wire_polys[:, :8] = _dev_fr(mont([(low[2 * j + t] - bs[j][t]) % r for j in range(W) for t in range(2)])).view(W, 8)
-        wire_polys[:, n4:n4 + 8] = _dev_fr(mont([b for row in bs for b in row])).view(W, 8)
-        wires_poly_comms_vec = gather_points(commit([wire_polys[j] for j in range(W)], [n + 2] * W))
-        for comms in wires_poly_comms_vec:
-            tr.append_commitments(b"witness_poly_comms", comms)
-
-        # ---- Round 2
-        beta = tr.get_challenge(b"beta")
-        gamma = tr.get_challenge(b"gamma")
-        bg = mont([beta, gamma])
-        b = [[H.fr_rand(cp, rng) for _ in range(3)] for _ in range(G)][me]
-        perm_poly = torch.zeros(l4, dtype=torch.int64, device="cuda")
-        L.plonk_perm_product_device(c, log_n, W, wire_vals.data_ptr(), pk.id_perm_vals.data_ptr(),
-                                    pk.sigma_vals.data_ptr(), bg[0], bg[1], perm_poly.data_ptr(), stream=st)
-        L.ntt_device(c, perm_poly.data_ptr(), log_n, 1, inverse=True, stream=st)
-        low = _read_fr(cp, perm_poly[:12])
-        perm_poly[:12] = _dev_fr(mont([(x - y) % r for x, y in zip(low, b)]))
-        perm_poly[n4:n4 + 12] = _dev_fr(mont(b))
-        prod_perm_poly_comms_vec = [row[0] for row in gather_points(commit([perm_poly], [n + 3]))]
-        tr.append_commitments(b"perm_poly_comms", prod_perm_poly_comms_vec)
-
-        # ---- Round 3: this rank's share alpha^(3 me) t_me of the quotient
-        alpha = tr.get_challenge(b"alpha")
-        alpha_base = pow(alpha, 3 * me, r)
-        NSEL = N_TURBO_PLONK_SELECTORS
-        if pk.coset_evals is not None:
-            fixed = pk.coset_evals
-            if fixed.shape != (NSEL + W, m * 4) or pk.coset_slice != (0, 1):
-                raise PlonkError("proving key coset evaluations were kept for another slice of the quotient coset")
-            npolys, o_w = W + 2, 0
-            sel_ptr, sig_ptr = fixed[0].data_ptr(), fixed[NSEL].data_ptr()
-        else:
-            npolys, o_w = NSEL + 2 * W + 2, NSEL + W
-        o_z, o_pi = o_w + W, o_w + W + 1
-        cs = torch.empty(npolys, m * 4, dtype=torch.int64, device="cuda")
-        cs[:, n4:l4].zero_()
-        if pk.coset_evals is None:
-            cs[:NSEL, :n4].copy_(pk.selectors)
-            cs[NSEL:o_w, :n4].copy_(pk.sigmas)
-            sel_ptr, sig_ptr = cs[0].data_ptr(), cs[NSEL].data_ptr()
-        cs[o_w:o_z, :l4].copy_(wire_polys)
-        cs[o_z, :l4].copy_(perm_poly)
-        cs[o_pi, :n4].copy_(pub_poly)
-        zmask = sum(1 << j for j, z in enumerate(pk.selector_is_zero) if z) if SKIP_ZERO_POLYS else 0
-        pi_zero = SKIP_ZERO_POLYS and not pub_input
-        zero_rows = [o_pi] if pi_zero else []
-        if pk.coset_evals is None:
-            zero_rows += [j for j in range(NSEL) if (zmask >> j) & 1]
-        _coset_ntt_rows(c, cs, zero_rows, log_m, gen, ln, st)
-        quot = torch.zeros(m * 4, dtype=torch.int64, device="cuda")
-        L.plonk_quotient_masked_device(c, W, log_n, log_m, gen, sel_ptr, sig_ptr, cs[o_w].data_ptr(), cs[o_z].data_ptr(),
-                                       0 if pi_zero else cs[o_pi].data_ptr(), 0, mont(vk.k),
-                                       mont([alpha, beta, gamma, alpha_base]), zmask, quot.data_ptr(), stream=st)
-        del cs
-        L.ntt_device(c, quot.data_ptr(), log_m, 1, inverse=True, coset_mont=gen, stream=st)
-        expected_degree = W * (n + 1) + 2
-        tail_nonzero = int(bool(torch.any(quot[(expected_degree + 1) * 4:] != 0).item()))
-        top = _read_fr(cp, quot[expected_degree * 4:(expected_degree + 1) * 4])[0]
-        checks = gather_ints([tail_nonzero, top])
-        if any(t for t, _ in checks) or sum(x for _, x in checks) % r == 0:
-            raise PlonkError("WrongQuotientPolyDegree(expected %d)" % expected_degree)
-        split = torch.zeros(W, l4, dtype=torch.int64, device="cuda")
-        step = (n + 2) * 4
-        for i in range(W - 1):
-            split[i, :step].copy_(quot[i * step:(i + 1) * step])
-        last_len = expected_degree + 1 - (W - 1) * (n + 2)
-        split[W - 1, :last_len * 4].copy_(quot[(W - 1) * step:(expected_degree + 1) * 4])
-        del quot
-        randomizers = [H.fr_rand(cp, rng) for _ in range(W - 1)]     # drawn on every rank, applied to instance 0's share
-        if me == 0:
-            firsts = _read_fr(cp, split[:, :4].contiguous())
-            last_randomizer = 0
-            for i in range(W - 1):
-                firsts[i] = (firsts[i] - last_randomizer) % r
-                split[i, step:step + 4] = _dev_fr(mont([randomizers[i]]))
-                last_randomizer = randomizers[i]
-            firsts[W - 1] = (firsts[W - 1] - last_randomizer) % r
-            split[:, :4] = _dev_fr(mont(firsts)).view(W, 4)
-        split_lens = [n + 3] * (W - 1) + [last_len]
-        split_quot_poly_comms = aggregated_commit([split[j] for j in range(W)], split_lens)
-        tr.append_commitments(b"quot_poly_comms", split_quot_poly_comms)
-
-        # ---- Round 4
-        zeta = tr.get_challenge(b"zeta")
-        zeta_omega = zeta * group_gen % r
-        zm, zom = mont([zeta])[0], mont([zeta_omega])[0]
-        evals_dev = torch.zeros((2 * W) * 4, dtype=torch.int64, device="cuda")
-        at_zeta = [(wire_polys[j], n + 2) for j in range(W)] + [(pk.sigmas[j], n) for j in range(W - 1)]
-        L.poly_eval_batch_device(c, [p.data_ptr() for p, _ in at_zeta], [k for _, k in at_zeta], zm,
-                                 evals_dev.data_ptr(), stream=st)
-        L.poly_eval_batch_device(c, [perm_poly.data_ptr()], [n + 3], zom, evals_dev.data_ptr() + (2 * W - 1) * 32,
-                                 stream=st)
-        poly_evals_vec = []
-        for ev in gather_ints(_read_fr(cp, evals_dev)):
-            pe = ProofEvaluations(ev[:W], ev[W:2 * W - 1], ev[2 * W - 1])
-            tr.append_field_elems(b"wire_evals", pe.wires_evals)
-            tr.append_field_elems(b"wire_sigma_evals", pe.wire_sigma_evals)
-            tr.append_field_elems(b"perm_next_eval", [pe.perm_next_eval])
-            poly_evals_vec.append(pe)
-        # this rank's share of the linearisation polynomial: quotient part over its split share + its instance's part
-        vanish_eval = (pow(zeta, n, r) - 1) % r
-        zeta_to_n_plus_2 = (vanish_eval + 1) * zeta % r * zeta % r
-        lagrange_1_eval = vanish_eval * pow(n * (zeta - 1) % r, -1, r) % r
-        terms = []
-        coeff = 1
-        for i in range(W):
-            if i:
-                coeff = coeff * zeta_to_n_plus_2 % r
-            terms.append((-vanish_eval * coeff % r, split[i], split_lens[i]))
-        pe = poly_evals_vec[me]
-        w = pe.wires_evals
-        q_scalars = [w[0], w[1], w[2], w[3], w[0] * w[1], w[2] * w[3], pow(w[0], 5, r), pow(w[1], 5, r), pow(w[2], 5, r),
-                     pow(w[3], 5, r), -w[4], 1, w[0] * w[1] * w[2] * w[3] * w[4]]
-        terms += [(s % r * alpha_base % r, pk.selectors[j], n) for j, s in enumerate(q_scalars)]
-        cz = alpha
-        for j in range(W):
-            cz = cz * (w[j] + beta * vk.k[j] % r * zeta + gamma) % r
-        cz = (cz + alpha * alpha % r * lagrange_1_eval) % r
-        terms.append((cz * alpha_base % r, perm_poly, n + 3))
-        csig = alpha * beta % r * pe.perm_next_eval % r
-        for j in range(W - 1):
-            csig = csig * (w[j] + beta * pe.wire_sigma_evals[j] + gamma) % r
-        terms.append((-csig * alpha_base % r, pk.sigmas[W - 1], n))
-        lin_share = lincomb(terms, n + 3)
-
-        # ---- Round 5: this rank's share of the two batched opening polynomials; division by (X - z) is linear too
-        v = tr.get_challenge(b"v")
-        cur = pow(v, 1 + me * (2 * W - 1), r)
-        open_terms = [(1, lin_share, n + 3)]
-        for p, k in at_zeta:
-            open_terms.append((cur, p, k))
-            cur = cur * v % r
-        open_share = lincomb(open_terms, n + 3)
-        shifted_share = lincomb([(pow(v, me, r), perm_poly, n + 3)], n + 3)
-        wpoly = torch.zeros(2, l4, dtype=torch.int64, device="cuda")
-        L.poly_divide_linear_device(c, open_share.data_ptr(), n + 3, zm, wpoly[0].data_ptr(), stream=st)
-        L.poly_divide_linear_device(c, shifted_share.data_ptr(), n + 3, zom, wpoly[1].data_ptr(), stream=st)
-        opening_proof, shifted_opening_proof = aggregated_commit([wpoly[0][4:], wpoly[1][4:]], [n + 2, n + 2])
-        return BatchProof(c, wires_poly_comms_vec, prod_perm_poly_comms_vec, poly_evals_vec, split_quot_poly_comms,
-                          opening_proof, shifted_opening_proof)
+                          opening_proof, shifted_opening_proof, plookup_proofs_vec)

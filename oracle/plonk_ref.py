@@ -1,5 +1,5 @@
-"""Big-integer restatement of jellyfish's TurboPlonk prover, preprocessor and verifier -- the checker for
-jellyfish_amd/plonk.py.
+"""Big-integer restatement of jellyfish's TurboPlonk / UltraPlonk (Plookup) prover, preprocessor and verifier -- the
+checker for jellyfish_amd/plonk.py.
 
 TEST INFRASTRUCTURE ONLY (see oracle/pyref.py).  Follows, function by function:
   * circuit builder / finalisation     relation/src/constraint_system.rs:406-470, 652-790, 831-884, 943-981,
@@ -11,7 +11,12 @@ TEST INFRASTRUCTURE ONLY (see oracle/pyref.py).  Follows, function by function:
                                        894-1015
   * transcript                         plonk/src/transcript/mod.rs:46-186, standard.rs:14-39 (Merlin: oracle/merlin.py)
   * verifier                           plonk/src/proof_system/verifier.rs:70-257, 262-339, 358-432, 439-535, 541-713,
-                                       718-788, 883-912
+                                       718-788, 831-864, 883-912
+  * UltraPlonk / Plookup               circuit: constraint_system.rs:304-312, 445-481, 604-648, 845-864, 1071-1107,
+                                       1171-1179, 1460-1688, gadgets/ultraplonk/lookup_table.rs:21-71, gates/lookup.rs;
+                                       prover: snark.rs:254-318, 346-362, 402-415, prover.rs:99-124, 147-178, 233-296,
+                                       421-453, 766-882, 1017-1087; structs.rs:208-221, 460-536, 899-931;
+                                       lagrange.rs:89-115; transcript/mod.rs:155-162
 External pieces restated from their published algorithms (crates absent from /root/reference, "ark, unverified
 here"): rand_chacha 0.3 ChaCha{12,20}Rng word stream, ark-ff 0.5 `Fp::rand` (limbs from next_u64, top bits shaved,
 rejection; the draw is the Montgomery representation), ark-serialize 0.5 compressed encodings (BN254: little-endian x
@@ -257,72 +262,109 @@ def ser_g2(cv: R.Curve, P) -> bytes:
     return bytes(b)
 
 
+PLOOKUP_EVAL_FIELDS = ("range_table_eval", "key_table_eval", "table_dom_sep_eval", "q_dom_sep_eval", "h_1_eval",
+                       "q_lookup_eval", "prod_next_eval", "range_table_next_eval", "key_table_next_eval",
+                       "table_dom_sep_next_eval", "h_1_next_eval", "h_2_next_eval", "q_lookup_next_eval", "w_3_next_eval",
+                       "w_4_next_eval")   # declaration (= serialisation) order of PlookupEvaluations, structs.rs:462-507
+
+
+def plookup_evals_vec(ev: dict):
+    """PlookupEvaluations::evals_vec (structs.rs:511-520): the transcript / opening order at zeta"""
+    return [ev[k] for k in ("range_table_eval", "key_table_eval", "h_1_eval", "q_lookup_eval", "table_dom_sep_eval",
+                            "q_dom_sep_eval")]
+
+
+def plookup_next_evals_vec(ev: dict):
+    """PlookupEvaluations::next_evals_vec (structs.rs:523-535): the order at zeta * g"""
+    return [ev[k] for k in ("prod_next_eval", "range_table_next_eval", "key_table_next_eval", "h_1_next_eval",
+                            "h_2_next_eval", "q_lookup_next_eval", "w_3_next_eval", "w_4_next_eval",
+                            "table_dom_sep_next_eval")]
+
+
+def _ser_vec_g1(cv, out, v):
+    out.extend(len(v).to_bytes(8, "little"))
+    for P in v:
+        out.extend(ser_g1(cv, P))
+
+
+def _ser_vec_fr(cv, out, v):
+    out.extend(len(v).to_bytes(8, "little"))
+    for x in v:
+        out.extend(ser_fr(cv, x))
+
+
+def _ser_plookup_proof(cv, out, pp):
+    """Option<PlookupProof> (structs.rs:208-221): one flag byte, then h_poly_comms, prod_lookup_poly_comm, poly_evals"""
+    if pp is None:
+        out.append(0)
+        return
+    out.append(1)
+    _ser_vec_g1(cv, out, pp["h_poly_comms"])
+    out.extend(ser_g1(cv, pp["prod_lookup_poly_comm"]))
+    for k in PLOOKUP_EVAL_FIELDS:
+        out.extend(ser_fr(cv, pp["poly_evals"][k]))
+
+
 def ser_proof(cv: R.Curve, proof: dict) -> bytes:
-    """CanonicalSerialize (compressed) of `Proof` (plonk/src/proof_system/structs.rs:54-76), TurboPlonk"""
+    """CanonicalSerialize (compressed) of `Proof` (plonk/src/proof_system/structs.rs:54-76)"""
     out = bytearray()
-
-    def vec_g1(v):
-        out.extend(len(v).to_bytes(8, "little"))
-        for P in v:
-            out.extend(ser_g1(cv, P))
-
-    def vec_fr(v):
-        out.extend(len(v).to_bytes(8, "little"))
-        for x in v:
-            out.extend(ser_fr(cv, x))
-
-    vec_g1(proof["wires_poly_comms"])
+    _ser_vec_g1(cv, out, proof["wires_poly_comms"])
     out.extend(ser_g1(cv, proof["prod_perm_poly_comm"]))
-    vec_g1(proof["split_quot_poly_comms"])
+    _ser_vec_g1(cv, out, proof["split_quot_poly_comms"])
     out.extend(ser_g1(cv, proof["opening_proof"]))
     out.extend(ser_g1(cv, proof["shifted_opening_proof"]))
-    vec_fr(proof["wires_evals"])
-    vec_fr(proof["wire_sigma_evals"])
+    _ser_vec_fr(cv, out, proof["wires_evals"])
+    _ser_vec_fr(cv, out, proof["wire_sigma_evals"])
     out.extend(ser_fr(cv, proof["perm_next_eval"]))
-    out.append(0)  # plookup_proof: None
+    _ser_plookup_proof(cv, out, proof.get("plookup_proof"))
     return bytes(out)
 
 
 def ser_batch_proof(cv: R.Curve, bp: dict) -> bytes:
-    """CanonicalSerialize (compressed) of `BatchProof` (plonk/src/proof_system/structs.rs:227-249), TurboPlonk
-    instances (plookup_proofs_vec = [None; k])"""
+    """CanonicalSerialize (compressed) of `BatchProof` (plonk/src/proof_system/structs.rs:227-249)"""
     out = bytearray()
-
-    def vec_g1(v):
-        out.extend(len(v).to_bytes(8, "little"))
-        for P in v:
-            out.extend(ser_g1(cv, P))
-
-    def vec_fr(v):
-        out.extend(len(v).to_bytes(8, "little"))
-        for x in v:
-            out.extend(ser_fr(cv, x))
-
     k = len(bp["prod_perm_poly_comms_vec"])
     out.extend(k.to_bytes(8, "little"))
     for comms in bp["wires_poly_comms_vec"]:
-        vec_g1(comms)
-    vec_g1(bp["prod_perm_poly_comms_vec"])
+        _ser_vec_g1(cv, out, comms)
+    _ser_vec_g1(cv, out, bp["prod_perm_poly_comms_vec"])
     out.extend(k.to_bytes(8, "little"))
     for ev in bp["poly_evals_vec"]:
-        vec_fr(ev["wires_evals"])
-        vec_fr(ev["wire_sigma_evals"])
+        _ser_vec_fr(cv, out, ev["wires_evals"])
+        _ser_vec_fr(cv, out, ev["wire_sigma_evals"])
         out.extend(ser_fr(cv, ev["perm_next_eval"]))
     out.extend(k.to_bytes(8, "little"))
-    out.extend(b"\x00" * k)  # plookup_proofs_vec: None each
-    vec_g1(bp["split_quot_poly_comms"])
+    for pp in bp.get("plookup_proofs_vec") or [None] * k:
+        _ser_plookup_proof(cv, out, pp)
+    _ser_vec_g1(cv, out, bp["split_quot_poly_comms"])
     out.extend(ser_g1(cv, bp["opening_proof"]))
     out.extend(ser_g1(cv, bp["shifted_opening_proof"]))
     return bytes(out)
 
 
 def batch_proof_from_proof(proof: dict) -> dict:
-    """impl From<Proof> for BatchProof (structs.rs:275-287)"""
-    return {"wires_poly_comms_vec": [proof["wires_poly_comms"]], "prod_perm_poly_comms_vec": [proof["prod_perm_poly_comm"]],
-            "poly_evals_vec": [{"wires_evals": proof["wires_evals"], "wire_sigma_evals": proof["wire_sigma_evals"],
-                                "perm_next_eval": proof["perm_next_eval"]}],
-            "split_quot_poly_comms": proof["split_quot_poly_comms"], "opening_proof": proof["opening_proof"],
-            "shifted_opening_proof": proof["shifted_opening_proof"]}
+    """impl From<Proof> for BatchProof (structs.rs:275-287).  TurboPlonk dicts carry no Plookup keys at all."""
+    bp = {"wires_poly_comms_vec": [proof["wires_poly_comms"]], "prod_perm_poly_comms_vec": [proof["prod_perm_poly_comm"]],
+          "poly_evals_vec": [{"wires_evals": proof["wires_evals"], "wire_sigma_evals": proof["wire_sigma_evals"],
+                              "perm_next_eval": proof["perm_next_eval"]}],
+          "split_quot_poly_comms": proof["split_quot_poly_comms"], "opening_proof": proof["opening_proof"],
+          "shifted_opening_proof": proof["shifted_opening_proof"]}
+    if proof.get("plookup_proof") is not None:
+        bp["plookup_proofs_vec"] = [proof["plookup_proof"]]
+    return bp
+
+
+def proof_from_batch_proof(bp: dict) -> dict:
+    """the single-instance `Proof` of a one-instance BatchProof"""
+    assert len(bp["prod_perm_poly_comms_vec"]) == 1
+    ev = bp["poly_evals_vec"][0]
+    proof = {"wires_poly_comms": bp["wires_poly_comms_vec"][0], "prod_perm_poly_comm": bp["prod_perm_poly_comms_vec"][0],
+             "split_quot_poly_comms": bp["split_quot_poly_comms"], "opening_proof": bp["opening_proof"],
+             "shifted_opening_proof": bp["shifted_opening_proof"], "wires_evals": ev["wires_evals"],
+             "wire_sigma_evals": ev["wire_sigma_evals"], "perm_next_eval": ev["perm_next_eval"]}
+    if bp.get("plookup_proofs_vec") and bp["plookup_proofs_vec"][0] is not None:
+        proof["plookup_proof"] = bp["plookup_proofs_vec"][0]
+    return proof
 
 
 # ------------------------------------------------------------------------------------------------
@@ -334,28 +376,52 @@ def _gate(q_lc=(0, 0, 0, 0), q_mul=(0, 0), q_hash=(0, 0, 0, 0), q_o=0, q_c=0, q_
     return list(q_lc) + list(q_mul) + list(q_hash) + [q_o, q_c, q_ecc]
 
 
-class PlonkCircuit:
-    """TurboPlonk subset of `PlonkCircuit` (constraint_system.rs:347-470, 558-790)"""
+RANGE_WIRE_ID = 5          # constraint_system.rs:304-312
+LOOKUP_KEY_WIRE_ID, LOOKUP_VAL_1_WIRE_ID, LOOKUP_VAL_2_WIRE_ID = 0, 1, 2
+TABLE_VAL_1_WIRE_ID, TABLE_VAL_2_WIRE_ID = 3, 4
+NO_LOOKUP = (0, 0, 0, 0)   # (q_lookup, q_dom_sep, table_key, table_dom_sep) of every non-lookup gate (gates/mod.rs:55-69)
 
-    def __init__(self, cv: R.Curve):
+
+class PlonkCircuit:
+    """`PlonkCircuit` (constraint_system.rs:347-470, 558-790): TurboPlonk, or UltraPlonk when range_bit_len is given
+    (new_ultra_plonk, :445-448: a 6th wire type for range gates, a q_lookup selector, key-value lookup tables)."""
+
+    def __init__(self, cv: R.Curve, range_bit_len: int | None = None):
         self.cv = cv
         self.r = cv.fr.p
-        self.num_wire_types = GATE_WIDTH + 1
+        self.ultra = range_bit_len is not None
+        self.range_bit_len = range_bit_len
+        self.num_wire_types = GATE_WIDTH + 1 + (1 if self.ultra else 0)
         self.witness = [0, 1]
         self.gates: list[list[int]] = []           # 13 selector values per gate
+        self.lk: list[tuple] = []                  # (q_lookup, q_dom_sep, table_key, table_dom_sep) per gate
         self.is_io: list[bool] = []
-        self.wire_variables = [[] for _ in range(GATE_WIDTH + 1)]
+        self.wire_variables = [[] for _ in range(self.num_wire_types)]
         self.pub_input_gate_ids: list[int] = []
+        self.table_gate_ids: list[tuple] = []      # (first gate id, length) of every inserted table
+        self.num_table_elems = 0
         self.n = 0                                  # eval domain size once finalised
         self.enforce_constant(0, 0)
         self.enforce_constant(1, 1)
 
+    @classmethod
+    def new_ultra_plonk(cls, cv: R.Curve, range_bit_len: int) -> "PlonkCircuit":
+        return cls(cv, range_bit_len)
+
+    def support_lookup(self) -> bool:
+        return self.ultra
+
+    def range_size(self) -> int:
+        assert self.ultra, "call range_size() with non-ultraplonk circuit"
+        return 1 << self.range_bit_len
+
     # -- builder ---------------------------------------------------------------------------------
-    def _insert_gate(self, wire_vars, sel, io=False):
+    def _insert_gate(self, wire_vars, sel, io=False, lk=NO_LOOKUP):
         assert self.n == 0, "ModifyFinalizedCircuit"
-        for w, v in zip(self.wire_variables, wire_vars):
+        for w, v in zip(self.wire_variables, wire_vars):   # the first GATE_WIDTH + 1 wire types (:461-466)
             w.append(v)
         self.gates.append(sel)
+        self.lk.append(lk)
         self.is_io.append(io)
 
     def num_gates(self):
@@ -402,6 +468,35 @@ class PlonkCircuit:
         self._insert_gate([a, 0, 0, 0, c], _gate(q_hash=(1, 0, 0, 0), q_o=1))
         return c
 
+    def add_range_check_variable(self, var: int):
+        """:475-481: the variable joins the range wire (wire type 5); it is looked up in [0, range_size)"""
+        assert self.ultra, "WrongPlonkType"
+        assert self.n == 0, "ModifyFinalizedCircuit"
+        assert 0 <= var < len(self.witness), "VarIndexOutOfBound"
+        self.wire_variables[RANGE_WIRE_ID].append(var)
+
+    def create_table_and_lookup_variables(self, lookup_vars, table_vars):
+        """gadgets/ultraplonk/lookup_table.rs:21-71: a key-value table (keys 0..len-1, values = pairs of variables) and
+        a list of (key, val0, val1) variable triples to look up in it; one LookupGate per row of max(len, len)"""
+        assert self.ultra, "WrongPlonkType"
+        for t in list(lookup_vars) + list(table_vars):
+            for v in t:
+                assert 0 <= v < len(self.witness), "VarIndexOutOfBound"
+        cnt = max(len(lookup_vars), len(table_vars))
+        self.table_gate_ids.append((self.num_gates(), cnt))
+        table_ctr = len(self.table_gate_ids)
+        for i in range(cnt):
+            if i < len(lookup_vars):
+                q_dom_sep, (key, val0, val1) = table_ctr, lookup_vars[i]
+            else:
+                q_dom_sep, (key, val0, val1) = 0, (0, 0, 0)
+            if i < len(table_vars):
+                table_dom_sep, table_key, (tv0, tv1) = table_ctr, i, table_vars[i]
+            else:
+                table_dom_sep, table_key, (tv0, tv1) = 0, 0, (0, 0)
+            self._insert_gate([key, val0, val1, tv0, tv1], _gate(), lk=(1, q_dom_sep, table_key, table_dom_sep))
+        self.num_table_elems += cnt
+
     def public_input(self):
         return [self.witness[self.wire_variables[GATE_WIDTH][g]] for g in self.pub_input_gate_ids]
 
@@ -409,26 +504,44 @@ class PlonkCircuit:
     def finalize_for_arithmetization(self):
         if self.n:
             return
+        slots = self.num_gates()
+        if self.ultra:
+            # range gates and lookup gates need separate slots (:1171-1179)
+            slots = max(slots, max(self.range_size(), len(self.wire_variables[RANGE_WIRE_ID])) + self.num_table_elems + 1)
         n = 1
-        while n < self.num_gates():
+        while n < slots:
             n <<= 1
         self.n = n
         self.log_n = n.bit_length() - 1
         # pad (constraint_system.rs:874-884): PaddingGate = all-zero selectors, wires = zero variable
         while len(self.gates) < n:
             self.gates.append(_gate())
+            self.lk.append(NO_LOOKUP)
             self.is_io.append(False)
         for w in self.wire_variables:
             w.extend([0] * (n - len(w)))
-        # rearrange_gates (:831-844): io gates to the front
+
+        def swap(a, b):   # gate types and the GATE_WIDTH + 1 gate wires; the range wire stays (:836-840, 855-859)
+            self.gates[a], self.gates[b] = self.gates[b], self.gates[a]
+            self.lk[a], self.lk[b] = self.lk[b], self.lk[a]
+            self.is_io[a], self.is_io[b] = self.is_io[b], self.is_io[a]
+            for w in self.wire_variables[:GATE_WIDTH + 1]:
+                w[a], w[b] = w[b], w[a]
+
+        # rearrange_gates (:831-866): io gates to the front ...
         for gate_id in range(len(self.pub_input_gate_ids)):
             io_gate_id = self.pub_input_gate_ids[gate_id]
             if io_gate_id > gate_id:
-                self.gates[gate_id], self.gates[io_gate_id] = self.gates[io_gate_id], self.gates[gate_id]
-                self.is_io[gate_id], self.is_io[io_gate_id] = self.is_io[io_gate_id], self.is_io[gate_id]
-                for w in self.wire_variables:
-                    w[gate_id], w[io_gate_id] = w[io_gate_id], w[gate_id]
+                swap(gate_id, io_gate_id)
                 self.pub_input_gate_ids[gate_id] = gate_id
+        # ... and the table lookup gates to the rear (never the very last slot), relative order kept
+        if self.ultra:
+            cur = n - 2
+            for (table_gate_id, table_size) in reversed(self.table_gate_ids):
+                for gate_id in reversed(range(table_gate_id, table_gate_id + table_size)):
+                    if gate_id < cur:
+                        swap(gate_id, cur)
+                        cur -= 1
         # compute_wire_permutation (:943-981)
         W = self.num_wire_types
         var_wires = [[] for _ in range(len(self.witness))]
@@ -458,11 +571,27 @@ class PlonkCircuit:
                    + sel[12] * w[0] * w[1] * w[2] * w[3] * w[4]) % r
             if lhs != sel[10] * w[4] % r:
                 return False
+        if self.ultra:   # range gates and key-value lookups (:604-648)
+            if any(self.witness[v] >= self.range_size() for v in self.wire_variables[RANGE_WIRE_ID]):
+                return False
+            wv = lambda i, g: self.witness[self.wire_variables[i][g]] if g < len(self.wire_variables[i]) else 0  # noqa: E731
+            table = {(0, 0, 0, 0)}
+            for gid, (ql, _, key, dom) in enumerate(self.lk):
+                if ql:
+                    table.add((dom, key, wv(TABLE_VAL_1_WIRE_ID, gid), wv(TABLE_VAL_2_WIRE_ID, gid)))
+            for gid, (ql, qdom, _, _) in enumerate(self.lk):
+                if ql and (qdom, wv(LOOKUP_KEY_WIRE_ID, gid), wv(LOOKUP_VAL_1_WIRE_ID, gid),
+                           wv(LOOKUP_VAL_2_WIRE_ID, gid)) not in table:
+                    return False
         return True
 
     # -- arithmetisation (:1359-1456) --------------------------------------------------------------
     def selector_values(self):
-        return [[g[s] for g in self.gates] for s in range(N_SELECTORS_TURBO)]
+        """all_selectors (:1093-1108): q_lc, q_mul, q_hash, q_o, q_c, q_ecc [, q_lookup]"""
+        sel = [[g[s] for g in self.gates] for s in range(N_SELECTORS_TURBO)]
+        if self.ultra:
+            sel.append(self.q_lookup_vec())
+        return sel
 
     def extended_permutation(self):
         n = self.n
@@ -490,6 +619,65 @@ class PlonkCircuit:
                 b = b * (tmp + beta * self.extended_id_permutation[pi * n + pj]) % r
             prod.append(prod[-1] * a % r * pow(b, -1, r) % r)
         return prod
+
+    # -- Plookup arithmetisation (:1071-1088, 1460-1688) ---------------------------------------------
+    def q_lookup_vec(self):
+        return [t[0] for t in self.lk]
+
+    def q_dom_sep_vec(self):
+        return [t[1] for t in self.lk]
+
+    def table_key_vec(self):
+        return [t[2] for t in self.lk]
+
+    def table_dom_sep_vec(self):
+        return [t[3] for t in self.lk]
+
+    def range_table(self):
+        """compute_range_table (:1630-1645): 0 .. range_size - 1, zero-padded to the domain"""
+        assert self.n >= self.range_size()
+        return list(range(self.range_size())) + [0] * (self.n - self.range_size())
+
+    def merged_lookup_table(self, tau):
+        """compute_merged_lookup_table / merged_table_value (:1495-1514, 1648-1667)"""
+        r = self.r
+        rt = self.range_table()
+        out = []
+        for i, (ql, _, key, dom) in enumerate(self.lk):
+            v1 = self.witness[self.wire_variables[TABLE_VAL_1_WIRE_ID][i]]
+            v2 = self.witness[self.wire_variables[TABLE_VAL_2_WIRE_ID][i]]
+            out.append((rt[i] + ql * tau % r * (dom + tau * (key + tau * (v1 + tau * v2)))) % r)
+        return out
+
+    def merged_lookup_wire_values(self, tau):
+        """merged_lookup_wire_value for every gate (:1670-1687)"""
+        r = self.r
+        out = []
+        for i, (ql, qdom, _, _) in enumerate(self.lk):
+            w = [self.witness[self.wire_variables[j][i]] for j in (RANGE_WIRE_ID, LOOKUP_KEY_WIRE_ID, LOOKUP_VAL_1_WIRE_ID,
+                                                                   LOOKUP_VAL_2_WIRE_ID)]
+            out.append((w[0] + ql * tau % r * (qdom + tau * (w[1] + tau * (w[2] + tau * w[3])))) % r)
+        return out
+
+    def lookup_sorted_vec(self, tau, merged_table):
+        """compute_lookup_sorted_vec_polynomials (:1577-1624) up to the two iffts: the 2n - 1 sorted concatenation"""
+        n = self.n
+        counts: dict = {}
+        for e in self.merged_lookup_wire_values(tau)[:n - 1]:   # only the first n - 1 variables are for lookup
+            counts[e] = counts.get(e, 0) + 1
+        out = []
+        for e in merged_table:
+            if e in counts:
+                out.extend([e] * (1 + counts.pop(e)))
+            else:
+                out.append(e)
+        if len(out) != 2 * n - 1:
+            raise ValueError("The sorted vector has wrong length, some lookup variables might be outside the table")
+        return out
+
+    def lookup_prod_values(self, tau, beta, gamma, merged_table, sorted_vec):
+        """compute_lookup_prod_polynomial (:1516-1575) before its ifft"""
+        return R.lookup_product(self.cv, self.merged_lookup_wire_values(tau), merged_table, sorted_vec, beta, gamma)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -520,6 +708,17 @@ def preprocess(cv: R.Curve, srs: dict, cs: PlonkCircuit):
           "sigma_comms": [_commit(cv, srs, p) for p in sigmas], "k": list(cs.k),
           "g": srs["g"], "h": srs["h"], "beta_h": srs["beta_h"]}
     pk = {"selectors": selectors, "sigmas": sigmas, "vk": vk, "srs": srs}
+    if cs.support_lookup():
+        # PlookupProvingKey / PlookupVerifyingKey (snark.rs:508-521, 537-557)
+        ppk = {"range_table_poly": R.ifft(cv, cs.range_table(), cs.log_n),
+               "key_table_poly": R.ifft(cv, cs.table_key_vec(), cs.log_n),
+               "table_dom_sep_poly": R.ifft(cv, cs.table_dom_sep_vec(), cs.log_n),
+               "q_dom_sep_poly": R.ifft(cv, cs.q_dom_sep_vec(), cs.log_n)}
+        pk["plookup_pk"] = ppk
+        vk["plookup_vk"] = {"range_table_comm": _commit(cv, srs, ppk["range_table_poly"]),
+                            "key_table_comm": _commit(cv, srs, ppk["key_table_poly"]),
+                            "table_dom_sep_comm": _commit(cv, srs, ppk["table_dom_sep_poly"]),
+                            "q_dom_sep_comm": _commit(cv, srs, ppk["q_dom_sep_poly"])}
     return pk, vk
 
 
@@ -588,119 +787,36 @@ def _lincomb(r, terms, length):
     return out
 
 
-def prove(cv: R.Curve, rng, cs: PlonkCircuit, pk: dict, extra_msg: bytes | None = None):
-    """PlonkKzgSnark::prove for one TurboPlonk instance (snark.rs:587-613 -> 163-430).
-    Returns (proof dict, challenges dict, oracles dict)."""
+def eval_merged_table(r, tau, range_eval, key_eval, q_lookup_eval, w3_eval, w4_eval, table_dom_sep_eval):
+    """structs.rs:899-914"""
+    return (range_eval + q_lookup_eval * tau % r * (table_dom_sep_eval + tau * (key_eval + tau * (w3_eval + tau * w4_eval)))) % r
+
+
+def eval_merged_lookup_witness(r, tau, w_range_eval, w_0_eval, w_1_eval, w_2_eval, q_lookup_eval, q_dom_sep_eval):
+    """structs.rs:916-931"""
+    return (w_range_eval + q_lookup_eval * tau % r * (q_dom_sep_eval + tau * (w_0_eval + tau * (w_1_eval + tau * w_2_eval)))) % r
+
+
+def first_and_last_lagrange_coeffs(cv: R.Curve, log_n: int, tau: int):
+    """plonk/src/lagrange.rs:89-115 for the plain domain (offset 1): (L_0(tau), L_{n-1}(tau))"""
     r = cv.fr.p
-    n, log_n, W = cs.n, cs.log_n, cs.num_wire_types
-    srs, vk = pk["srs"], pk["vk"]
-    m = 1
-    while m < n * ((W * (n + 1) + 2) // n + 1):
-        m <<= 1
-    log_m = m.bit_length() - 1
-    gen = cv.fr_generator
-    tr = StandardTranscript(cv)
-    if extra_msg is not None:
-        tr.append_message(b"extra info", extra_msg)
-    tr.append_vk_and_pub_input(vk, cs.public_input())
-    # Round 1
-    wire_polys = [_mask(cv, rng, R.ifft(cv, v, log_n), n, 1) for v in cs.wire_values()]
-    wires_poly_comms = [_commit(cv, srs, p) for p in wire_polys]
-    pub_inp_poly = R.ifft(cv, cs.pub_input_values(), log_n)
-    tr.append_commitments(b"witness_poly_comms", wires_poly_comms)
-    # Round 2
-    beta = tr.get_challenge(b"beta")
-    gamma = tr.get_challenge(b"gamma")
-    prod_perm_poly = _mask(cv, rng, R.ifft(cv, cs.prod_permutation_values(beta, gamma), log_n), n, 2)
-    prod_perm_poly_comm = _commit(cv, srs, prod_perm_poly)
-    tr.append_commitments(b"perm_poly_comms", [prod_perm_poly_comm])
-    # Round 3
-    alpha = tr.get_challenge(b"alpha")
-    sel_c = [R.fft(cv, p, log_m, gen) for p in pk["selectors"]]
-    sig_c = [R.fft(cv, p, log_m, gen) for p in pk["sigmas"]]
-    wir_c = [R.fft(cv, p, log_m, gen) for p in wire_polys]
-    z_c = R.fft(cv, prod_perm_poly, log_m, gen)
-    pi_c = R.fft(cv, pub_inp_poly, log_m, gen)
-    quot_evals = R.quotient_evals_turbo(cv, log_n, log_m, sel_c, sig_c, wir_c, z_c, pi_c, cs.k, alpha, beta, gamma)
-    quot = R.ifft(cv, quot_evals, log_m, gen)
-    while quot and quot[-1] == 0:
-        quot.pop()
-    expected_degree = W * (n + 1) + 2
-    if len(quot) - 1 != expected_degree:
-        raise ValueError("WrongQuotientPolyDegree(%d, %d)" % (len(quot) - 1, expected_degree))
-    split = []
-    for i in range(W):
-        end = (i + 1) * (n + 2) if i < W - 1 else len(quot)
-        split.append(quot[i * (n + 2):end])
-    last = 0
-    for i in range(W - 1):
-        now = fr_rand(cv, rng)
-        split[i][0] = (split[i][0] - last) % r
-        split[i].append(now)
-        last = now
-    split[W - 1][0] = (split[W - 1][0] - last) % r
-    split_quot_poly_comms = [_commit(cv, srs, p) for p in split]
-    tr.append_commitments(b"quot_poly_comms", split_quot_poly_comms)
-    # Round 4
-    zeta = tr.get_challenge(b"zeta")
-    g = R.domain_root(cv, log_n)
-    wires_evals = [R.poly_eval(cv, p, zeta) for p in wire_polys]
-    wire_sigma_evals = [R.poly_eval(cv, p, zeta) for p in pk["sigmas"][:W - 1]]
-    perm_next_eval = R.poly_eval(cv, prod_perm_poly, zeta * g % r)
-    tr.append_field_elems(b"wire_evals", wires_evals)
-    tr.append_field_elems(b"wire_sigma_evals", wire_sigma_evals)
-    tr.append_field_elems(b"perm_next_eval", [perm_next_eval])
-    # linearisation polynomial (prover.rs:299-352, 946-1015)
-    vanish_eval = (pow(zeta, n, r) - 1) % r
-    zeta_n2 = (vanish_eval + 1) * zeta % r * zeta % r
-    terms = []
-    coeff = 1
-    for i, t in enumerate(split):
-        if i:
-            coeff = coeff * zeta_n2 % r
-        terms.append((-vanish_eval * coeff, t))
-    w = wires_evals
-    sel = pk["selectors"]
-    q_scalars = [w[0], w[1], w[2], w[3], w[0] * w[1], w[2] * w[3], pow(w[0], 5, r), pow(w[1], 5, r), pow(w[2], 5, r),
-                 pow(w[3], 5, r), -w[4], 1, w[0] * w[1] * w[2] * w[3] * w[4]]
-    terms += [(s, p) for s, p in zip(q_scalars, sel)]
-    lagrange_1 = vanish_eval * pow(n * (zeta - 1), -1, r) % r
-    c_z = alpha
-    for j in range(W):
-        c_z = c_z * (w[j] + beta * vk["k"][j] % r * zeta + gamma) % r
-    c_z = (c_z + alpha * alpha % r * lagrange_1) % r
-    terms.append((c_z, prod_perm_poly))
-    c_s = alpha * beta % r * perm_next_eval % r
-    for j in range(W - 1):
-        c_s = c_s * (w[j] + beta * wire_sigma_evals[j] + gamma) % r
-    terms.append((-c_s, pk["sigmas"][W - 1]))
-    lin_poly = _lincomb(r, terms, n + 3)
-    # Round 5
-    v = tr.get_challenge(b"v")
-    polys = [lin_poly] + wire_polys + pk["sigmas"][:W - 1]
-    batch, c = [], 1
-    for p in polys:
-        batch.append((c, p))
-        c = c * v % r
-    batch_poly = _lincomb(r, batch, n + 3)
-    q, _ = R.witness_poly(cv, batch_poly, zeta)
-    opening_proof = _commit(cv, srs, q)
-    q, _ = R.witness_poly(cv, prod_perm_poly, zeta * g % r)
-    shifted_opening_proof = _commit(cv, srs, q)
-    proof = {"wires_poly_comms": wires_poly_comms, "prod_perm_poly_comm": prod_perm_poly_comm,
-             "split_quot_poly_comms": split_quot_poly_comms, "opening_proof": opening_proof,
-             "shifted_opening_proof": shifted_opening_proof, "wires_evals": wires_evals,
-             "wire_sigma_evals": wire_sigma_evals, "perm_next_eval": perm_next_eval}
-    challenges = {"beta": beta, "gamma": gamma, "alpha": alpha, "zeta": zeta, "v": v}
-    oracles = {"wire_polys": wire_polys, "prod_perm_poly": prod_perm_poly, "pub_inp_poly": pub_inp_poly,
-               "split_quot_polys": split, "lin_poly": lin_poly}
-    return proof, challenges, oracles
+    n = 1 << log_n
+    g_inv = pow(R.domain_root(cv, log_n), -1, r)
+    if tau == 1:
+        return 1, 0
+    if tau == g_inv:
+        return 0, 1
+    z = (pow(tau, n, r) - 1) % r
+    if z == 0:
+        return 0, 0
+    return z * pow(n * (tau - 1), -1, r) % r, z * g_inv % r * pow(n * (tau - g_inv), -1, r) % r
 
 
-def batch_prove(cv: R.Curve, rng, circuits, pks, extra_msg: bytes | None = None):
-    """PlonkKzgSnark::batch_prove for k TurboPlonk instances -> one BatchProof (snark.rs:61-74 -> 163-430): per round
-    the instances run in order on the ONE rng and the ONE transcript; the quotient is sum_i alpha^(3i) t_i
-    (prover.rs:519-656), the opening polynomials fold all instances (prover.rs:356-413)."""
+def _prove_internal(cv: R.Curve, rng, circuits, pks, extra_msg):
+    """PlonkKzgSnark::batch_prove_internal (snark.rs:163-430): k instances (TurboPlonk and / or UltraPlonk) -> one
+    BatchProof.  Per round the instances run in order on the ONE rng and the ONE transcript; the quotient is
+    sum_i alpha_base_i t_i with alpha_base advancing by alpha^3 (alpha^7 after a Plookup instance, prover.rs:519-656);
+    the opening polynomials fold all instances (prover.rs:356-413)."""
     r = cv.fr.p
     if not circuits:
         raise ValueError("zero number of circuits/proving keys")
@@ -712,6 +828,15 @@ def batch_prove(cv: R.Curve, rng, circuits, pks, extra_msg: bytes | None = None)
             raise ValueError("circuit domain size %d != expected domain size %d" % (cs.n, n))
         if pk["vk"]["domain_size"] != n:
             raise ValueError("proving key domain size %d != expected domain size %d" % (pk["vk"]["domain_size"], n))
+        if len(cs.pub_input_gate_ids) != pk["vk"]["num_inputs"]:
+            raise ValueError("circuit.num_inputs %d != prove_key.num_inputs %d"
+                             % (len(cs.pub_input_gate_ids), pk["vk"]["num_inputs"]))
+        if cs.support_lookup() != ("plookup_pk" in pk):
+            raise ValueError("Mismatched Plonk types between the proving key and the circuit")
+        if cs.num_wire_types != W:
+            raise ValueError("inconsistent plonk circuit types")
+    K = len(circuits)
+    lookup = [cs.support_lookup() for cs in circuits]
     srs = pks[0]["srs"]
     m = 1
     while m < n * ((W * (n + 1) + 2) // n + 1):
@@ -719,6 +844,7 @@ def batch_prove(cv: R.Curve, rng, circuits, pks, extra_msg: bytes | None = None)
     log_m = m.bit_length() - 1
     gen = cv.fr_generator
     g = R.domain_root(cv, log_n)
+    g_inv = pow(g, -1, r)
     tr = StandardTranscript(cv)
     if extra_msg is not None:
         tr.append_message(b"extra info", extra_msg)
@@ -733,6 +859,19 @@ def batch_prove(cv: R.Curve, rng, circuits, pks, extra_msg: bytes | None = None)
         pub_polys_v.append(R.ifft(cv, cs.pub_input_values(), log_n))
         tr.append_commitments(b"witness_poly_comms", comms)
         wires_comms_v.append(comms)
+    # Round 1.5 (Plookup, snark.rs:254-284; prover.rs:99-124)
+    tau = tr.get_challenge(b"tau") if any(lookup) else None
+    h_polys_v, h_comms_v, sorted_v, table_v = [None] * K, [None] * K, [None] * K, [None] * K
+    for i, (cs, pk) in enumerate(zip(circuits, pks)):
+        if not lookup[i]:
+            continue
+        table_v[i] = cs.merged_lookup_table(tau)
+        sorted_v[i] = cs.lookup_sorted_vec(tau, table_v[i])
+        h1 = _mask(cv, rng, R.ifft(cv, sorted_v[i][:n], log_n), n, 2)
+        h2 = _mask(cv, rng, R.ifft(cv, sorted_v[i][n - 1:], log_n), n, 2)
+        h_polys_v[i] = [h1, h2]
+        h_comms_v[i] = [_commit(cv, pk["srs"], h1), _commit(cv, pk["srs"], h2)]
+        tr.append_commitments(b"h_poly_comms", h_comms_v[i])
     # Round 2
     beta = tr.get_challenge(b"beta")
     gamma = tr.get_challenge(b"gamma")
@@ -743,20 +882,42 @@ def batch_prove(cv: R.Curve, rng, circuits, pks, extra_msg: bytes | None = None)
         tr.append_commitments(b"perm_poly_comms", [c])
         perm_polys_v.append(z)
         perm_comms_v.append(c)
+    # Round 2.5 (Plookup, snark.rs:298-318; prover.rs:147-178)
+    pl_polys_v, pl_comms_v = [None] * K, [None] * K
+    for i, (cs, pk) in enumerate(zip(circuits, pks)):
+        if not lookup[i]:
+            continue
+        vals = cs.lookup_prod_values(tau, beta, gamma, table_v[i], sorted_v[i])
+        pl_polys_v[i] = _mask(cv, rng, R.ifft(cv, vals, log_n), n, 2)
+        pl_comms_v[i] = _commit(cv, pk["srs"], pl_polys_v[i])
+        tr.append_commitments(b"plookup_poly_comms", [pl_comms_v[i]])
     # Round 3
     alpha = tr.get_challenge(b"alpha")
     alpha_3 = pow(alpha, 3, r)
+    alpha_7 = pow(alpha, 7, r)
     quot_evals = [0] * m
+    alpha_bases = []
     alpha_base = 1
     for i, (cs, pk) in enumerate(zip(circuits, pks)):
+        alpha_bases.append(alpha_base)
         sel_c = [R.fft(cv, p, log_m, gen) for p in pk["selectors"]]
         sig_c = [R.fft(cv, p, log_m, gen) for p in pk["sigmas"]]
         wir_c = [R.fft(cv, p, log_m, gen) for p in wire_polys_v[i]]
         z_c = R.fft(cv, perm_polys_v[i], log_m, gen)
         pi_c = R.fft(cv, pub_polys_v[i], log_m, gen)
-        ev = R.quotient_evals_turbo(cv, log_n, log_m, sel_c, sig_c, wir_c, z_c, pi_c, cs.k, alpha, beta, gamma, alpha_base)
+        if lookup[i]:
+            ppk = pk["plookup_pk"]
+            lk_c = [R.fft(cv, p, log_m, gen) for p in (ppk["range_table_poly"], ppk["key_table_poly"],
+                                                       ppk["table_dom_sep_poly"], ppk["q_dom_sep_poly"],
+                                                       h_polys_v[i][0], h_polys_v[i][1], pl_polys_v[i])]
+            ev = R.quotient_evals_ultra(cv, log_n, log_m, sel_c, sig_c, wir_c, z_c, pi_c, lk_c, cs.k, alpha, beta, gamma,
+                                        tau, alpha_base)
+            alpha_base = alpha_base * alpha_7 % r
+        else:
+            ev = R.quotient_evals_turbo(cv, log_n, log_m, sel_c, sig_c, wir_c, z_c, pi_c, cs.k, alpha, beta, gamma,
+                                        alpha_base)
+            alpha_base = alpha_base * alpha_3 % r
         quot_evals = [(a + b) % r for a, b in zip(quot_evals, ev)]
-        alpha_base = alpha_base * alpha_3 % r
     quot = R.ifft(cv, quot_evals, log_m, gen)
     while quot and quot[-1] == 0:
         quot.pop()
@@ -778,62 +939,130 @@ def batch_prove(cv: R.Curve, rng, circuits, pks, extra_msg: bytes | None = None)
     tr.append_commitments(b"quot_poly_comms", split_quot_poly_comms)
     # Round 4
     zeta = tr.get_challenge(b"zeta")
+    zeta_g = zeta * g % r
     evals_v = []
     for i, pk in enumerate(pks):
         ev = {"wires_evals": [R.poly_eval(cv, p, zeta) for p in wire_polys_v[i]],
               "wire_sigma_evals": [R.poly_eval(cv, p, zeta) for p in pk["sigmas"][:W - 1]],
-              "perm_next_eval": R.poly_eval(cv, perm_polys_v[i], zeta * g % r)}
+              "perm_next_eval": R.poly_eval(cv, perm_polys_v[i], zeta_g)}
         tr.append_field_elems(b"wire_evals", ev["wires_evals"])
         tr.append_field_elems(b"wire_sigma_evals", ev["wire_sigma_evals"])
         tr.append_field_elems(b"perm_next_eval", [ev["perm_next_eval"]])
         evals_v.append(ev)
+    # Round 4.5 (Plookup, snark.rs:346-362; prover.rs:233-296)
+    pl_evals_v = [None] * K
+    for i, pk in enumerate(pks):
+        if not lookup[i]:
+            continue
+        ppk = pk["plookup_pk"]
+        q_lookup_poly = pk["selectors"][-1]
+        h1, h2 = h_polys_v[i]
+        at = lambda p, x: R.poly_eval(cv, p, x)  # noqa: E731
+        pe = {"range_table_eval": at(ppk["range_table_poly"], zeta), "key_table_eval": at(ppk["key_table_poly"], zeta),
+              "h_1_eval": at(h1, zeta), "q_lookup_eval": at(q_lookup_poly, zeta),
+              "table_dom_sep_eval": at(ppk["table_dom_sep_poly"], zeta), "q_dom_sep_eval": at(ppk["q_dom_sep_poly"], zeta),
+              "prod_next_eval": at(pl_polys_v[i], zeta_g), "range_table_next_eval": at(ppk["range_table_poly"], zeta_g),
+              "key_table_next_eval": at(ppk["key_table_poly"], zeta_g), "h_1_next_eval": at(h1, zeta_g),
+              "h_2_next_eval": at(h2, zeta_g), "q_lookup_next_eval": at(q_lookup_poly, zeta_g),
+              "w_3_next_eval": at(wire_polys_v[i][3], zeta_g), "w_4_next_eval": at(wire_polys_v[i][4], zeta_g),
+              "table_dom_sep_next_eval": at(ppk["table_dom_sep_poly"], zeta_g)}
+        tr.append_field_elems(b"plookup_evals", plookup_evals_vec(pe))
+        tr.append_field_elems(b"plookup_next_evals", plookup_next_evals_vec(pe))
+        pl_evals_v[i] = pe
+    # linearisation polynomial (snark.rs:364-389; prover.rs:299-352, 946-1087)
     vanish_eval = (pow(zeta, n, r) - 1) % r
     zeta_n2 = (vanish_eval + 1) * zeta % r * zeta % r
-    lagrange_1 = vanish_eval * pow(n * (zeta - 1), -1, r) % r
+    lagrange_1, lagrange_n = first_and_last_lagrange_coeffs(cv, log_n, zeta)
     terms = []
     coeff = 1
     for i, t in enumerate(split):
         if i:
             coeff = coeff * zeta_n2 % r
         terms.append((-vanish_eval * coeff, t))
-    alpha_base = 1
     for i, pk in enumerate(pks):
+        ab = alpha_bases[i]
         w, sig_e, znext = evals_v[i]["wires_evals"], evals_v[i]["wire_sigma_evals"], evals_v[i]["perm_next_eval"]
         q_scalars = [w[0], w[1], w[2], w[3], w[0] * w[1], w[2] * w[3], pow(w[0], 5, r), pow(w[1], 5, r), pow(w[2], 5, r),
                      pow(w[3], 5, r), -w[4], 1, w[0] * w[1] * w[2] * w[3] * w[4]]
-        terms += [(alpha_base * s, p) for s, p in zip(q_scalars, pk["selectors"])]
+        terms += [(ab * s, p) for s, p in zip(q_scalars, pk["selectors"])]   # q_lookup (14th) is not in r_circ
         c_z = alpha
         for j in range(W):
             c_z = c_z * (w[j] + beta * pk["vk"]["k"][j] % r * zeta + gamma) % r
         c_z = (c_z + alpha * alpha % r * lagrange_1) % r
-        terms.append((alpha_base * c_z, perm_polys_v[i]))
+        terms.append((ab * c_z, perm_polys_v[i]))
         c_s = alpha * beta % r * znext % r
         for j in range(W - 1):
             c_s = c_s * (w[j] + beta * sig_e[j] + gamma) % r
-        terms.append((-c_s * alpha_base, pk["sigmas"][W - 1]))
-        alpha_base = alpha_base * alpha_3 % r
+        terms.append((-c_s * ab, pk["sigmas"][W - 1]))
+        if lookup[i]:
+            pe = pl_evals_v[i]
+            a4, a5, a6 = pow(alpha, 4, r), pow(alpha, 5, r), pow(alpha, 6, r)
+            mt = eval_merged_table(r, tau, pe["range_table_eval"], pe["key_table_eval"], pe["q_lookup_eval"], w[3], w[4],
+                                   pe["table_dom_sep_eval"])
+            mt_next = eval_merged_table(r, tau, pe["range_table_next_eval"], pe["key_table_next_eval"],
+                                        pe["q_lookup_next_eval"], pe["w_3_next_eval"], pe["w_4_next_eval"],
+                                        pe["table_dom_sep_next_eval"])
+            ml = eval_merged_lookup_witness(r, tau, w[5], w[0], w[1], w[2], pe["q_lookup_eval"], pe["q_dom_sep_eval"])
+            b1 = (1 + beta) % r
+            zmg = (zeta - g_inv) % r
+            c_p = (a4 * lagrange_1 + a5 * lagrange_n
+                   + a6 * zmg % r * b1 % r * (gamma + ml) % r * (gamma * b1 + mt + beta * mt_next)) % r
+            terms.append((ab * c_p, pl_polys_v[i]))
+            c_h2 = -a6 * zmg % r * pe["prod_next_eval"] % r * (gamma * b1 + pe["h_1_eval"] + beta * pe["h_1_next_eval"]) % r
+            terms.append((ab * c_h2, h_polys_v[i][1]))
     lin_poly = _lincomb(r, terms, n + 3)
-    # Round 5
+    # Round 5 (prover.rs:356-453)
     v = tr.get_challenge(b"v")
     polys = [lin_poly]
     for i, pk in enumerate(pks):
         polys += wire_polys_v[i] + pk["sigmas"][:W - 1]
+        if lookup[i]:
+            ppk = pk["plookup_pk"]
+            polys += [ppk["range_table_poly"], ppk["key_table_poly"], h_polys_v[i][0], pk["selectors"][-1],
+                      ppk["table_dom_sep_poly"], ppk["q_dom_sep_poly"]]
     batch, c = [], 1
     for p in polys:
         batch.append((c, p))
         c = c * v % r
     q, _ = R.witness_poly(cv, _lincomb(r, batch, n + 3), zeta)
     opening_proof = _commit(cv, srs, q)
+    polys = []
+    for i, pk in enumerate(pks):
+        polys.append(perm_polys_v[i])
+        if lookup[i]:
+            ppk = pk["plookup_pk"]
+            polys += [pl_polys_v[i], ppk["range_table_poly"], ppk["key_table_poly"], h_polys_v[i][0], h_polys_v[i][1],
+                      pk["selectors"][-1], wire_polys_v[i][3], wire_polys_v[i][4], ppk["table_dom_sep_poly"]]
     batch, c = [], 1
-    for z in perm_polys_v:
-        batch.append((c, z))
+    for p in polys:
+        batch.append((c, p))
         c = c * v % r
-    q, _ = R.witness_poly(cv, _lincomb(r, batch, n + 3), zeta * g % r)
+    q, _ = R.witness_poly(cv, _lincomb(r, batch, n + 3), zeta_g)
     shifted_opening_proof = _commit(cv, srs, q)
     bp = {"wires_poly_comms_vec": wires_comms_v, "prod_perm_poly_comms_vec": perm_comms_v, "poly_evals_vec": evals_v,
           "split_quot_poly_comms": split_quot_poly_comms, "opening_proof": opening_proof,
           "shifted_opening_proof": shifted_opening_proof}
-    challenges = {"beta": beta, "gamma": gamma, "alpha": alpha, "zeta": zeta, "v": v}
+    if any(lookup):
+        bp["plookup_proofs_vec"] = [None if not lookup[i] else
+                                    {"h_poly_comms": h_comms_v[i], "prod_lookup_poly_comm": pl_comms_v[i],
+                                     "poly_evals": pl_evals_v[i]} for i in range(K)]
+    challenges = {"tau": tau, "beta": beta, "gamma": gamma, "alpha": alpha, "zeta": zeta, "v": v}
+    oracles = [{"wire_polys": wire_polys_v[i], "prod_perm_poly": perm_polys_v[i], "pub_inp_poly": pub_polys_v[i],
+                "h_polys": h_polys_v[i], "prod_lookup_poly": pl_polys_v[i], "split_quot_polys": split,
+                "lin_poly": lin_poly} for i in range(K)]
+    return bp, challenges, oracles
+
+
+def prove(cv: R.Curve, rng, cs: PlonkCircuit, pk: dict, extra_msg: bytes | None = None):
+    """PlonkKzgSnark::prove for one instance (snark.rs:587-613 -> 163-430).
+    Returns (proof dict, challenges dict, oracles dict); an UltraPlonk proof carries a "plookup_proof" entry."""
+    bp, challenges, oracles = _prove_internal(cv, rng, [cs], [pk], extra_msg)
+    return proof_from_batch_proof(bp), challenges, oracles[0]
+
+
+def batch_prove(cv: R.Curve, rng, circuits, pks, extra_msg: bytes | None = None):
+    """PlonkKzgSnark::batch_prove (snark.rs:61-74 -> 163-430) -> (BatchProof dict, challenges)"""
+    bp, challenges, _ = _prove_internal(cv, rng, circuits, pks, extra_msg)
     return bp, challenges
 
 
@@ -844,117 +1073,37 @@ def batch_prove(cv: R.Curve, rng, circuits, pks, extra_msg: bytes | None = None)
 
 def verify(cv: R.Curve, vk: dict, pub_input, proof: dict, extra_msg: bytes | None = None, trapdoor_beta: int | None = None,
            pairing_check=None) -> bool:
-    """PlonkKzgSnark::verify for one TurboPlonk proof (verifier.rs).  The final check e(A, [beta]h) == e(B, h) is
-    evaluated by `pairing_check(A, beta_h, B, h)` if given, else as [trapdoor_beta]A == B."""
-    r = cv.fr.p
-    n = vk["domain_size"]
-    log_n = n.bit_length() - 1
-    W = len(proof["wires_poly_comms"])
-    if len(pub_input) != vk["num_inputs"]:
-        return False
-    for P in (proof["wires_poly_comms"] + proof["split_quot_poly_comms"]
-              + [proof["prod_perm_poly_comm"], proof["opening_proof"], proof["shifted_opening_proof"]]):
-        if not R.on_curve(cv, P):
-            return False
-    # compute_challenges (:262-339)
-    tr = StandardTranscript(cv)
-    if extra_msg is not None:
-        tr.append_message(b"extra info", extra_msg)
-    tr.append_vk_and_pub_input(vk, pub_input)
-    tr.append_commitments(b"witness_poly_comms", proof["wires_poly_comms"])
-    beta = tr.get_challenge(b"beta")
-    gamma = tr.get_challenge(b"gamma")
-    tr.append_commitments(b"perm_poly_comms", [proof["prod_perm_poly_comm"]])
-    alpha = tr.get_challenge(b"alpha")
-    tr.append_commitments(b"quot_poly_comms", proof["split_quot_poly_comms"])
-    zeta = tr.get_challenge(b"zeta")
-    tr.append_field_elems(b"wire_evals", proof["wires_evals"])
-    tr.append_field_elems(b"wire_sigma_evals", proof["wire_sigma_evals"])
-    tr.append_field_elems(b"perm_next_eval", [proof["perm_next_eval"]])
-    v = tr.get_challenge(b"v")
-    tr.append_commitments(b"open_proof", [proof["opening_proof"]])
-    tr.append_commitments(b"shifted_open_proof", [proof["shifted_opening_proof"]])
-    u = tr.get_challenge(b"u")
-
-    g = R.domain_root(cv, log_n)
-    alpha_2 = alpha * alpha % r
-    vanish_eval = (pow(zeta, n, r) - 1) % r
-    lagrange_1 = vanish_eval * pow(n * (zeta - 1), -1, r) % r
-    w = proof["wires_evals"]
-    sig = proof["wire_sigma_evals"]
-    znext = proof["perm_next_eval"]
-    # evaluate_pi_poly (:883-912): sum_i L_i(zeta) pub_input[i], L_i(z) = Z_H(z) g^i / (n (z - g^i))
-    pi_eval = 0
-    gi = 1
-    for x in pub_input:
-        pi_eval = (pi_eval + vanish_eval * gi % r * pow(n * (zeta - gi), -1, r) % r * x) % r
-        gi = gi * g % r
-    # compute_lin_poly_constant_term (:358-432)
-    tmp = (pi_eval - alpha_2 * lagrange_1) % r
-    acc = alpha * znext % r * (gamma + w[W - 1]) % r
-    for we, se in zip(w[:W - 1], sig):
-        acc = acc * (gamma + we + beta * se) % r
-    lin_poly_constant = (tmp - acc) % r
-    # linearization_scalars_and_bases (:541-713)
-    sb = []
-    coeff = alpha_2 * lagrange_1 % r
-    acc = alpha
-    for we, k in zip(w, vk["k"]):
-        acc = acc * (beta * k % r * zeta + gamma + we) % r
-    sb.append(((coeff + acc) % r, proof["prod_perm_poly_comm"]))
-    acc = alpha * beta % r * znext % r
-    for we, se in zip(w[:W - 1], sig):
-        acc = acc * (beta * se + gamma + we) % r
-    sb.append((-acc % r, vk["sigma_comms"][-1]))
-    q_scalars = [w[0], w[1], w[2], w[3], w[0] * w[1], w[2] * w[3], pow(w[0], 5, r), pow(w[1], 5, r), pow(w[2], 5, r),
-                 pow(w[3], 5, r), -w[4], 1, w[0] * w[1] * w[2] * w[3] * w[4]]
-    sb += [(s % r, c) for s, c in zip(q_scalars, vk["selector_comms"])]
-    zeta_n2 = (1 + vanish_eval) * zeta % r * zeta % r
-    coeff = -vanish_eval % r
-    sb.append((coeff, proof["split_quot_poly_comms"][0]))
-    for c in proof["split_quot_poly_comms"][1:]:
-        coeff = coeff * zeta_n2 % r
-        sb.append((coeff, c))
-    # aggregate_poly_commitments (:439-535) / aggregate_evaluations (:718-788)
-    v_base, uv_base = v, u
-    result = -lin_poly_constant % r
-    for c, e in zip(proof["wires_poly_comms"] + vk["sigma_comms"][:W - 1], w + sig):
-        sb.append((v_base, c))
-        result = (result + e * v_base) % r
-        v_base = v_base * v % r
-    sb.append((uv_base, proof["prod_perm_poly_comm"]))
-    result = (result + znext * uv_base) % r
-    # batch_verify_opening_proofs (:201-257), single instance (r = 1)
-    A = R.msm_naive(cv, [proof["opening_proof"], proof["shifted_opening_proof"]], [1, u])
-    next_eval_point = zeta * g % r
-    sb.append((zeta, proof["opening_proof"]))
-    sb.append((u * next_eval_point % r, proof["shifted_opening_proof"]))
-    sb.append((-result % r, vk["g"]))
-    B = R.msm_naive(cv, [c for _, c in sb], [s for s, _ in sb])
-    if pairing_check is not None:
-        return pairing_check(A, vk["beta_h"], B, vk["h"])
-    assert trapdoor_beta is not None
-    return R.ec_mul(cv, trapdoor_beta, A) == B
+    """PlonkKzgSnark::verify for one proof (snark.rs:615-630: the one-instance case of the batch verifier).  The final
+    check e(A, [beta]h) == e(B, h) is evaluated by `pairing_check(A, beta_h, B, h)` if given, else as
+    [trapdoor_beta]A == B."""
+    return verify_batch_proof(cv, [vk], [pub_input], batch_proof_from_proof(proof), extra_msg, trapdoor_beta, pairing_check)
 
 
 def verify_batch_proof(cv: R.Curve, vks, pub_inputs, bp: dict, extra_msg: bytes | None = None,
                        trapdoor_beta: int | None = None, pairing_check=None) -> bool:
-    """Verifier::prepare_pcs_info + batch_verify_opening_proofs for ONE BatchProof over k TurboPlonk instances
-    (verifier.rs:70-257, 262-339, 358-432, 439-535, 541-713, 718-788).  Final pairing check as in verify()."""
+    """Verifier::prepare_pcs_info + batch_verify_opening_proofs for ONE BatchProof over k instances, TurboPlonk and / or
+    UltraPlonk (verifier.rs:70-257, 262-339, 358-432, 439-535, 541-713, 718-788, 831-864)."""
     r = cv.fr.p
     k_inst = len(bp["prod_perm_poly_comms_vec"])
     if not (len(vks) == k_inst == len(pub_inputs)) or k_inst == 0:
         return False
+    pps = bp.get("plookup_proofs_vec") or [None] * k_inst
     n = vks[0]["domain_size"]
     log_n = n.bit_length() - 1
-    for vk, pi in zip(vks, pub_inputs):
+    for vk, pi, pp in zip(vks, pub_inputs, pps):
         if len(pi) != vk["num_inputs"] or vk["domain_size"] != n:
+            return False
+        if ("plookup_vk" in vk) != (pp is not None):
             return False
     pts = bp["split_quot_poly_comms"] + bp["prod_perm_poly_comms_vec"] + [bp["opening_proof"], bp["shifted_opening_proof"]]
     for comms in bp["wires_poly_comms_vec"]:
         pts = pts + comms
+    for pp in pps:
+        if pp is not None:
+            pts = pts + pp["h_poly_comms"] + [pp["prod_lookup_poly_comm"]]
     if not all(R.on_curve(cv, P) for P in pts):
         return False
+    # compute_challenges (:262-339)
     tr = StandardTranscript(cv)
     if extra_msg is not None:
         tr.append_message(b"extra info", extra_msg)
@@ -962,9 +1111,16 @@ def verify_batch_proof(cv: R.Curve, vks, pub_inputs, bp: dict, extra_msg: bytes 
         tr.append_vk_and_pub_input(vk, pi)
     for comms in bp["wires_poly_comms_vec"]:
         tr.append_commitments(b"witness_poly_comms", comms)
+    tau = tr.get_challenge(b"tau") if any("plookup_vk" in vk for vk in vks) else None
+    for pp in pps:
+        if pp is not None:
+            tr.append_commitments(b"h_poly_comms", pp["h_poly_comms"])
     beta = tr.get_challenge(b"beta")
     gamma = tr.get_challenge(b"gamma")
     tr.append_commitments(b"perm_poly_comms", bp["prod_perm_poly_comms_vec"])
+    for pp in pps:
+        if pp is not None:
+            tr.append_commitments(b"plookup_poly_comms", [pp["prod_lookup_poly_comm"]])
     alpha = tr.get_challenge(b"alpha")
     tr.append_commitments(b"quot_poly_comms", bp["split_quot_poly_comms"])
     zeta = tr.get_challenge(b"zeta")
@@ -972,17 +1128,27 @@ def verify_batch_proof(cv: R.Curve, vks, pub_inputs, bp: dict, extra_msg: bytes 
         tr.append_field_elems(b"wire_evals", ev["wires_evals"])
         tr.append_field_elems(b"wire_sigma_evals", ev["wire_sigma_evals"])
         tr.append_field_elems(b"perm_next_eval", [ev["perm_next_eval"]])
+    for pp in pps:
+        if pp is not None:
+            tr.append_field_elems(b"plookup_evals", plookup_evals_vec(pp["poly_evals"]))
+            tr.append_field_elems(b"plookup_next_evals", plookup_next_evals_vec(pp["poly_evals"]))
     v = tr.get_challenge(b"v")
     tr.append_commitments(b"open_proof", [bp["opening_proof"]])
     tr.append_commitments(b"shifted_open_proof", [bp["shifted_opening_proof"]])
     u = tr.get_challenge(b"u")
 
     g = R.domain_root(cv, log_n)
+    g_inv = pow(g, -1, r)
     alpha_2 = alpha * alpha % r
     alpha_3 = alpha_2 * alpha % r
-    alpha_bases = [pow(alpha_3, i, r) for i in range(k_inst)]
+    alpha_4, alpha_5, alpha_6, alpha_7 = (pow(alpha, e, r) for e in (4, 5, 6, 7))
+    # alpha_bases (:132-144): powers of alpha^7 when the FIRST key is UltraPlonk, else of alpha^3
+    step = alpha_7 if "plookup_vk" in vks[0] else alpha_3
+    alpha_bases = [pow(step, i, r) for i in range(k_inst)]
     vanish_eval = (pow(zeta, n, r) - 1) % r
-    lagrange_1 = vanish_eval * pow(n * (zeta - 1), -1, r) % r
+    lagrange_1, lagrange_n = first_and_last_lagrange_coeffs(cv, log_n, zeta)
+    b1 = (1 + beta) % r
+    gb = gamma * b1 % r
     lin_poly_constant = 0
     sb = []
     for i, (vk, pi) in enumerate(zip(vks, pub_inputs)):
@@ -990,16 +1156,28 @@ def verify_batch_proof(cv: R.Curve, vks, pub_inputs, bp: dict, extra_msg: bytes 
         w, sig, znext = ev["wires_evals"], ev["wire_sigma_evals"], ev["perm_next_eval"]
         W = len(w)
         ab = alpha_bases[i]
+        pp = pps[i]
+        # evaluate_pi_poly (:883-912): sum_i L_i(zeta) pub_input[i], L_i(z) = Z_H(z) g^i / (n (z - g^i))
         pi_eval = 0
         gi = 1
         for x in pi:
             pi_eval = (pi_eval + vanish_eval * gi % r * pow(n * (zeta - gi), -1, r) % r * x) % r
             gi = gi * g % r
+        # compute_lin_poly_constant_term (:358-432)
         tmp = (pi_eval - alpha_2 * lagrange_1) % r
         acc = alpha * znext % r * (gamma + w[W - 1]) % r
         for we, se in zip(w[:W - 1], sig):
             acc = acc * (gamma + we + beta * se) % r
-        lin_poly_constant = (lin_poly_constant + ab * (tmp - acc)) % r
+        tmp = (tmp - acc) % r
+        if pp is not None:
+            pe = pp["poly_evals"]
+            plookup_constant = (lagrange_n * (pe["h_1_eval"] - pe["h_2_next_eval"] - alpha_2) - alpha * lagrange_1
+                                - alpha_3 * (zeta - g_inv) % r * pe["prod_next_eval"] % r
+                                * (gb + pe["h_1_eval"] + beta * pe["h_1_next_eval"]) % r
+                                * (gb + beta * pe["h_2_next_eval"])) % r
+            tmp = (tmp + alpha_3 * plookup_constant) % r
+        lin_poly_constant = (lin_poly_constant + ab * tmp) % r
+        # linearization_scalars_and_bases (:541-713)
         coeff = alpha_2 * lagrange_1 % r
         acc = alpha
         for we, kk in zip(w, vk["k"]):
@@ -1012,24 +1190,57 @@ def verify_batch_proof(cv: R.Curve, vks, pub_inputs, bp: dict, extra_msg: bytes 
         q_scalars = [w[0], w[1], w[2], w[3], w[0] * w[1], w[2] * w[3], pow(w[0], 5, r), pow(w[1], 5, r),
                      pow(w[2], 5, r), pow(w[3], 5, r), -w[4], 1, w[0] * w[1] * w[2] * w[3] * w[4]]
         sb += [(s * ab % r, c) for s, c in zip(q_scalars, vk["selector_comms"])]
+        if pp is not None:
+            pe = pp["poly_evals"]
+            ml = eval_merged_lookup_witness(r, tau, w[5], w[0], w[1], w[2], pe["q_lookup_eval"], pe["q_dom_sep_eval"])
+            mt = eval_merged_table(r, tau, pe["range_table_eval"], pe["key_table_eval"], pe["q_lookup_eval"], w[3], w[4],
+                                   pe["table_dom_sep_eval"])
+            mt_next = eval_merged_table(r, tau, pe["range_table_next_eval"], pe["key_table_next_eval"],
+                                        pe["q_lookup_next_eval"], pe["w_3_next_eval"], pe["w_4_next_eval"],
+                                        pe["table_dom_sep_next_eval"])
+            coeff = (alpha_4 * lagrange_1 + alpha_5 * lagrange_n
+                     + alpha_6 * (zeta - g_inv) % r * b1 % r * (gamma + ml) % r * (gb + mt + beta * mt_next)) % r
+            sb.append((ab * coeff % r, pp["prod_lookup_poly_comm"]))
+            coeff = ab * alpha_6 % r * (g_inv - zeta) % r * pe["prod_next_eval"] % r \
+                * (gb + pe["h_1_eval"] + beta * pe["h_1_next_eval"]) % r
+            sb.append((coeff, pp["h_poly_comms"][1]))
     zeta_n2 = (1 + vanish_eval) * zeta % r * zeta % r
     coeff = -vanish_eval % r
     sb.append((coeff, bp["split_quot_poly_comms"][0]))
     for c in bp["split_quot_poly_comms"][1:]:
         coeff = coeff * zeta_n2 % r
         sb.append((coeff, c))
+    # aggregate_poly_commitments (:439-535) / aggregate_evaluations (:718-788)
     v_base, uv_base = v, u
     result = -lin_poly_constant % r
     for i, vk in enumerate(vks):
         ev = bp["poly_evals_vec"][i]
-        W = len(bp["wires_poly_comms_vec"][i])
-        for c, e in zip(bp["wires_poly_comms_vec"][i] + vk["sigma_comms"][:W - 1], ev["wires_evals"] + ev["wire_sigma_evals"]):
+        wc = bp["wires_poly_comms_vec"][i]
+        W = len(wc)
+        for c, e in zip(wc + vk["sigma_comms"][:W - 1], ev["wires_evals"] + ev["wire_sigma_evals"]):
             sb.append((v_base, c))
             result = (result + e * v_base) % r
             v_base = v_base * v % r
         sb.append((uv_base, bp["prod_perm_poly_comms_vec"][i]))
         result = (result + ev["perm_next_eval"] * uv_base) % r
         uv_base = uv_base * v % r
+        pp = pps[i]
+        if pp is not None:
+            pvk = vk["plookup_vk"]
+            q_lookup_comm = vk["selector_comms"][-1]
+            at_zeta = [pvk["range_table_comm"], pvk["key_table_comm"], pp["h_poly_comms"][0], q_lookup_comm,
+                       pvk["table_dom_sep_comm"], pvk["q_dom_sep_comm"]]
+            for c, e in zip(at_zeta, plookup_evals_vec(pp["poly_evals"])):
+                sb.append((v_base, c))
+                result = (result + e * v_base) % r
+                v_base = v_base * v % r
+            at_next = [pp["prod_lookup_poly_comm"], pvk["range_table_comm"], pvk["key_table_comm"], pp["h_poly_comms"][0],
+                       pp["h_poly_comms"][1], q_lookup_comm, wc[3], wc[4], pvk["table_dom_sep_comm"]]
+            for c, e in zip(at_next, plookup_next_evals_vec(pp["poly_evals"])):
+                sb.append((uv_base, c))
+                result = (result + e * uv_base) % r
+                uv_base = uv_base * v % r
+    # batch_verify_opening_proofs (:201-257), one BatchProof (r = 1)
     A = R.msm_naive(cv, [bp["opening_proof"], bp["shifted_opening_proof"]], [1, u])
     sb.append((zeta, bp["opening_proof"]))
     sb.append((u * (zeta * g % r) % r, bp["shifted_opening_proof"]))

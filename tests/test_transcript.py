@@ -192,3 +192,62 @@ def test_product_circuit_matches_oracle_circuit():
             b.check_circuit_satisfiability([5, 19])
         with pytest.raises(JP.PlonkError):
             b.create_variable(1)
+
+
+@pytest.mark.parametrize("cv", [R.BN254, R.BLS12_381], ids=lambda c: c.name)
+def test_oracle_ultraplonk_prove_verify(cv):
+    """the restated UltraPlonk (Plookup) prover against the restated verifier -- two restatements of different reference
+    files (prover.rs / verifier.rs) that must agree: range gates, two key-value tables, single proof and a 2-instance
+    BatchProof; tampered Plookup evaluations, a wrong public input and a swapped instance order are rejected"""
+    from tests.util import build_ultra_circuit
+
+    css = [build_ultra_circuit(P.PlonkCircuit.new_ultra_plonk(cv, 3), 4, e) for e in (0, 1)]
+    n = css[0].n
+    assert all(c.n == n for c in css) and all(c.check_circuit_satisfiability(c.public_input()) for c in css)
+    beta = 0x1234567890ABCDEF1234567890ABCDEF % cv.fr.p
+    srs = P.universal_setup_for_testing(cv, n + 2, beta)
+    keys = [P.preprocess(cv, srs, c) for c in css]
+    pks, vks = [k[0] for k in keys], [k[1] for k in keys]
+    pubs = [c.public_input() for c in css]
+    proof, ch, orc = P.prove(cv, P.test_rng(), css[0], pks[0])
+    assert ch["tau"] is not None and len(proof["wires_poly_comms"]) == 6 and len(proof["wire_sigma_evals"]) == 5
+    assert P.verify(cv, vks[0], pubs[0], proof, trapdoor_beta=beta)
+    # h_1 / h_2 interpolate the sorted vector; its halves overlap in one element (constraint_system.rs:1621-1622)
+    tau = ch["tau"]
+    srt = css[0].lookup_sorted_vec(tau, css[0].merged_lookup_table(tau))
+    assert len(srt) == 2 * n - 1 and srt[n - 1] == srt[:n][-1] == srt[n - 1:][0]
+    bad = dict(proof, plookup_proof=dict(proof["plookup_proof"], poly_evals=dict(proof["plookup_proof"]["poly_evals"])))
+    bad["plookup_proof"]["poly_evals"]["prod_next_eval"] = (bad["plookup_proof"]["poly_evals"]["prod_next_eval"] + 1) % cv.fr.p
+    assert not P.verify(cv, vks[0], pubs[0], bad, trapdoor_beta=beta)
+    assert not P.verify(cv, vks[0], [pubs[0][0] + 1, pubs[0][1]], proof, trapdoor_beta=beta)
+    q = 8 * cv.fq.limbs64
+    assert len(P.ser_proof(cv, proof)) == (8 + 6 * q) + q + (8 + 6 * q) + 2 * q + (8 + 6 * 32) + (8 + 5 * 32) + 32 + 1 \
+        + (8 + 2 * q) + q + 15 * 32
+    bp, _ = P.batch_prove(cv, P.test_rng(), css, pks)
+    assert P.verify_batch_proof(cv, vks, pubs, bp, trapdoor_beta=beta)
+    assert not P.verify_batch_proof(cv, vks[::-1], pubs[::-1], bp, trapdoor_beta=beta)
+    # an unsatisfied lookup has no sorted vector
+    broken = build_ultra_circuit(P.PlonkCircuit.new_ultra_plonk(cv, 3), 4)
+    broken.witness[broken.witness.index(114)] = 115
+    assert not broken.check_circuit_satisfiability(broken.public_input())
+    with pytest.raises(ValueError, match="sorted vector"):
+        P.prove(cv, P.test_rng(), broken, pks[0])
+
+
+@pytest.mark.parametrize("cv", [R.BN254, R.BLS12_381], ids=lambda c: c.name)
+def test_ultra_circuit_finalisation_matches_oracle(cv):
+    """pad / io gates to the front / lookup gates to the rear / permutation (constraint_system.rs:831-884, 1167-1187)"""
+    from jellyfish_amd import plonk as JP
+    from tests.util import build_ultra_circuit
+
+    ocs = build_ultra_circuit(P.PlonkCircuit.new_ultra_plonk(cv, 3), 10)
+    cs = build_ultra_circuit(JP.PlonkCircuit.new_ultra_plonk(cv.curve_id, 3), 10)
+    n = ocs.n
+    assert cs.eval_domain_size() == n and cs.k == ocs.k and cs.public_input() == ocs.public_input()
+    assert [list(map(int, row)) for row in cs.wire_variables] == ocs.wire_variables
+    assert [int(x) for x in cs.wire_permutation] == [w * n + g for (w, g) in ocs.wire_permutation]
+    kinds = [cs.gate_kinds[int(k)] for k in cs.gate_kind]
+    assert [list(k[:13]) for k in kinds] == ocs.gates
+    assert [tuple(k[13:]) for k in kinds] == ocs.lk
+    assert ocs.check_circuit_satisfiability(ocs.public_input())
+    cs.check_circuit_satisfiability(cs.public_input())

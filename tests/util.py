@@ -98,3 +98,27 @@ def ref_kat_cases():
         return int(x) % r
 
     return [(c["cite"], c["log_n"], [val(x) for x in c["evals"]], [val(x) for x in c["coeffs"]]) for c in g["cases"]], g
+
+
+def build_ultra_circuit(cs, size: int = 4, extra: int = 0):
+    """An UltraPlonk test circuit for both builders (oracle and product share the method names): arithmetic gates,
+    public inputs created out of order, range-checked variables and two key-value tables, one with fewer lookups than
+    rows and one with more (relation/src/gadgets/ultraplonk/lookup_table.rs:91-131 test shapes)."""
+    a = cs.create_variable(3)
+    b = cs.create_public_variable(5 + extra)
+    c = cs.mul(a, b)
+    d = cs.add(c, a)
+    for v in (a, b):
+        cs.add_range_check_variable(v)
+    cs.add_range_check_variable(cs.create_variable(6))
+    tv = [(cs.create_variable(10 + i), cs.create_variable(100 + 7 * i)) for i in range(4)]
+    lk = [(cs.create_variable(key), cs.create_variable(10 + key), cs.create_variable(100 + 7 * key)) for key in (2, 0, 2)]
+    cs.create_table_and_lookup_variables(lk, tv)
+    tv2 = [(cs.create_variable(55), cs.create_variable(66))]
+    lk2 = [(cs.create_variable(0), cs.create_variable(55), cs.create_variable(66)) for _ in range(3)]
+    cs.create_table_and_lookup_variables(lk2, tv2)
+    for i in range(size + extra):
+        d = cs.add(d, 1) if i % 3 else cs.mul(d, a)
+    cs.create_public_variable(cs.witness[d])
+    cs.finalize_for_arithmetization()
+    return cs
