@@ -231,3 +231,76 @@ def test_real_batch_prove_one_circuit_per_rank_is_byte_identical(world):
     for p in procs:
         p.join(timeout=30)
     assert sorted(res) == [(r, True) for r in range(world)], res
+
+
+def _ultra_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from jellyfish_amd import lib as L
+        from jellyfish_amd import plonk as JP
+        from tests.test_gpu_plonk import BETA
+        from tests.util import build_ultra_circuit
+
+        torch.cuda.set_device(0)
+        L.load_library()
+        L.init(0)
+        # one instance more than ranks: rank 0 proves instances 0 and `world`
+        css = [build_ultra_circuit(JP.PlonkCircuit.new_ultra_plonk(1, 4), 6, e) for e in range(world + 1)]   # b = 5 + e < 16
+        beta = BETA % css[0].r
+        srs = JP.PlonkKzgSnark.universal_setup_for_testing(1, css[0].eval_domain_size() + 2, beta)
+        keys = [JP.PlonkKzgSnark.preprocess(srs, c) for c in css]
+        pks = [k[0] for k in keys]
+        ref = JP.PlonkKzgSnark.batch_prove(JP.H.test_rng(), css[:world], pks[:world], b"cfg5").serialize_compressed()
+        # (a) BASELINE config 5's layout: one UltraPlonk circuit per rank
+        got = JP.PlonkKzgSnark.batch_prove_one_per_rank(JP.H.test_rng(), css[rank], pks[rank], b"cfg5")
+        ok = got.serialize_compressed() == ref and got.plookup_proofs_vec is not None and len(got) == world
+        # (b) point-range sharded commitments + coset-sliced quotient of the same batch
+        shard = JP.PlonkKzgSnark.batch_prove(JP.H.test_rng(), css[:world], pks[:world], b"cfg5", sharded=True)
+        ok = ok and shard.serialize_compressed() == ref
+        # (c) uneven placement: world + 1 instances, the last one on rank 0 as well
+        ref2 = JP.PlonkKzgSnark.batch_prove(JP.H.test_rng(), css, pks).serialize_compressed()
+        owners = list(range(world)) + [0]
+        mine_c = [c if owners[i] == rank else None for i, c in enumerate(css)]
+        mine_k = [k if owners[i] == rank else None for i, k in enumerate(pks)]
+        placed = JP.PlonkKzgSnark.batch_prove_placed(JP.H.test_rng(), mine_c, mine_k, owners)
+        ok = ok and placed.serialize_compressed() == ref2
+        # (d) a parameter error on ONE rank is raised on every rank (no rank left waiting in a collective)
+        bad_k = list(mine_k)
+        if rank == 1:
+            bad_k[1] = None
+        try:
+            JP.PlonkKzgSnark.batch_prove_placed(JP.H.test_rng(), mine_c, bad_k, owners)
+            ok = False
+        except JP.PlonkError as e:
+            ok = ok and "no circuit / proving key" in str(e)
+        q.put((rank, ok))
+    except Exception as e:
+        import traceback
+
+        q.put((rank, repr(e) + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_ultraplonk_batch_prove_across_ranks_is_byte_identical(world):
+    """BASELINE config 5 (UltraPlonk, BLS12-381, batch_prove with one circuit per GPU) with the ranks sharing cuda:0:
+    one-per-rank, sharded and unevenly placed batches all give the bytes of the one-GPU batch_prove; world 8 = m / n
+    runs the coset-slice fold of the Plookup polynomials (n + 3 coefficients mod X^n - c)."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ultra_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=400) for _ in procs]
+    for p in procs:
+        p.join(timeout=30)
+    assert sorted(res) == [(r, True) for r in range(world)], res
