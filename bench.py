@@ -280,49 +280,97 @@ BLS_G = np.array([0x5cb38790fd530c16, 0x7817fc679976fff5, 0x154f95c7143ba1c1, 0x
 
 
 def batch_prove_section(L, torch, dist, world, rank, stream, log_g):
-    """BASELINE config 5 shape: batch_prove of `world` independent UltraPlonk (Plookup) circuits of 2^log_g gates on
-    BLS12-381, one circuit per GPU; the only exchange is one all_gather of 18 group elements per rank
-    (jellyfish_amd/dist.py batch_prove_one_per_rank).  Synthetic inputs are generated on the device."""
+    """BASELINE config 5: PlonkKzgSnark::batch_prove of `world` independent UltraPlonk (Plookup) circuits of 2^log_g gates
+    on BLS12-381, one circuit per GPU, the REAL call: gen_circuit_for_bench(UltraPlonk, range_bit_len = 8)
+    (plonk/benches/bench.rs:29-46), StandardTranscript, blinding from test_rng, sorted-vector merge, 18 commitments per
+    instance + 8 aggregated ones.  N = 1 proves one circuit (prove = the one-instance batch); N > 1 runs
+    batch_prove_one_per_rank: per-instance commitments / evaluations gathered, aggregated commitments as group sums."""
     import hashlib
 
-    from jellyfish_amd import dist as jdist
-    from jellyfish_amd import prover_path as PP
+    from jellyfish_amd import hostglue as H
+    from jellyfish_amd import plonk as JP
 
-    def rand_dev(cnt, seed):
-        g = torch.Generator(device="cuda")
-        g.manual_seed(90000 + 1000 * rank + seed)
-        t = torch.randint(-(1 << 63), (1 << 63) - 1, (cnt, 4), dtype=torch.int64, device="cuda", generator=g)
-        t[:, 3] &= (1 << 60) - 1   # < 2^252 < r: valid Montgomery representatives
-        return t
-
-    beta = uniform_fr(1, 0x6A660005, BLS_R)[0]
-    srs_p = L.Srs.gen_for_testing(1, beta, BLS_G, (1 << log_g) + 8)
-    hp = PP.UltraPlonkHotPath(1, log_g, srs_p, rand_dev, stream)
-    jdist.batch_prove_one_per_rank(hp, L)
+    t0 = time.perf_counter()
+    cs = JP.PlonkCircuit.new_ultra_plonk(1, 8)
+    a = cs.create_variable(rank + 2) if world > 1 else cs.zero()
+    one = cs.one()
+    for _ in range((1 << log_g) - 10):
+        a = cs.add(a, one)
+    cs.finalize_for_arithmetization()
+    n = cs.eval_domain_size()
+    wit = H.fr_to_mont(cs.cp, cs.witness)
+    build_s = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    srs = JP.PlonkKzgSnark.universal_setup_for_testing(1, n + 2, 0x6A660005)
+    pk, vk = JP.PlonkKzgSnark.preprocess(srs, cs)
     torch.cuda.synchronize()
+    setup_s = time.perf_counter() - t0
+    rng = H.test_rng()
+
+    def run():
+        if world == 1:
+            return JP.PlonkKzgSnark.batch_prove(rng, [cs], [pk], witness_monts=[wit])
+        return JP.PlonkKzgSnark.batch_prove_one_per_rank(rng, cs, pk, witness_mont=wit)
+
+    first = run().serialize_compressed()
     ts = []
     for _ in range(3):
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        res = jdist.batch_prove_one_per_rank(hp, L)
+        run()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         if world > 1:
             dt = max_over_ranks(torch, dist, dt)
         ts.append(dt * 1e3)
-    sec = {"workload": "batch_prove, %d UltraPlonk (Plookup) BLS12-381 circuits of 2^%d gates, one per GPU: per circuit "
-                       "11 iNTT(n) + 35 coset NTT(8n) + 2 grand products + Plookup quotient + coset iNTT(8n) + 18 commitments + 27 evaluations"
-                       % (world, log_g),
-           "n_gpus": world, "ms": round(float(np.median(ts)), 3), "runs_ms": [round(t, 3) for t in ts],
-           "circuits_per_s": round(world / (float(np.median(ts)) * 1e-3), 3),
-           "excluded": "host transcript, RNG and the sorted lookup vector merge (inputs here)",
-           "aggregated_sha": hashlib.sha256(bytes(res["aggregated"].cpu().numpy().tobytes())).hexdigest()[:16]}
-    srs_p.free()
-    del hp
+    ms = float(np.median(ts))
+    JP.PROFILE = {}
+    run()
+    rounds = dict(JP.PROFILE)
+    JP.PROFILE = None
+    sec = {"workload": "PlonkKzgSnark::batch_prove, %d UltraPlonk (Plookup, range_bit_len 8) BLS12-381 bench circuits of "
+                       "2^%d gates, one per GPU -> one BatchProof; StandardTranscript, blinding from test_rng; per circuit "
+                       "11 iNTT(n) + 35 coset NTT(8n) + sorted-vector merge + 2 grand products + Plookup quotient + coset "
+                       "iNTT(8n) + 18 commitments + 27 evaluations" % (world, log_g),
+           "n_gpus": world, "instances": world, "domain_size": n,
+           "ms": round(ms, 3), "runs_ms": [round(t, 3) for t in ts],
+           "circuits_per_s": round(world / (ms * 1e-3), 3), "ns_per_gate": round(ms * 1e6 / (world << log_g), 2),
+           "rounds_ms_rank0_with_syncs": rounds,
+           "includes": "witness upload, all device work, host Merlin transcript + RNG, commitment / evaluation read-backs",
+           "setup_not_timed": {"circuit_build_s": round(build_s, 2), "srs_and_preprocess_s": round(setup_s, 2)},
+           "proof_bytes": len(first), "first_proof_sha": hashlib.sha256(first).hexdigest()[:16],
+           "parity": "BatchProof bytes equal oracle/plonk_ref.py and verify at small sizes, the 2^22-gate proof verifies; "
+                     "one-per-rank bytes equal the one-GPU batch_prove (tests/test_gpu_ultraplonk.py, "
+                     "tests/test_gpu_dist_prove.py)"}
+    srs.powers_of_g.free()
+    del pk
     torch.cuda.empty_cache()
     return sec
+
+
+def launch_ranks(n_gpus: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script (one per GPU, RCCL) through
+    torch.distributed.run and return its exit status.  Nothing here touches the GPU (no exec after GPU init)."""
+    import socket
+    import subprocess
+
+    import torch
+
+    have = torch.cuda.device_count()          # counting devices does not initialise the runtime
+    rehearse = os.environ.get("JF_BENCH_REHEARSE") == "1"
+    if have < n_gpus and not rehearse:
+        print("bench.py: --gpus %d asked for but only %d GPU(s) are visible; refusing to print a line for fewer GPUs "
+              "(JF_BENCH_REHEARSE=1 rehearses the N > 1 code path with all ranks on cuda:0 over gloo)" % (n_gpus, have),
+              file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
 
 
 def main():
@@ -338,6 +386,13 @@ def main():
                     help="also run BASELINE config 5: batch_prove of UltraPlonk BLS12-381 circuits of 2^K gates, "
                          "one circuit per GPU (config 5 is K = 22; 0 skips it)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        print("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks" % (args.gpus, os.environ.get("WORLD_SIZE")),
+              file=sys.stderr)
+        sys.exit(2)
 
     import torch
     import torch.distributed as dist
@@ -601,16 +656,19 @@ def main():
     import threading
 
     finished = threading.Event()
-    snapshot = {"out": copy.deepcopy(out)}
+    snapshot = {"out": copy.deepcopy(out), "section": "start"}
 
     def watchdog():
         if finished.wait(float(os.environ.get("JF_BENCH_SECONDARY_TIMEOUT_S", "600"))):
             return
+        # a stalled collective is a failure: say where, keep what was measured, exit non-zero
+        msg = "bench.py: rank %d stalled in section '%s' (a rank failed or hung inside a collective)" % (rank, snapshot["section"])
+        print(msg, file=sys.stderr, flush=True)
         if rank == 0 and snapshot["out"] is not None:
             line = snapshot["out"]
-            line["secondary_sections"] = "timed out; sections not listed here did not finish"
+            line["secondary_sections"] = "STALLED in '%s'; sections not listed here did not finish" % snapshot["section"]
             print(json.dumps(line), flush=True)
-        os._exit(0)
+        os._exit(3)
 
     if world > 1:
         threading.Thread(target=watchdog, daemon=True).start()
@@ -620,13 +678,18 @@ def main():
             out[key] = sec
             snapshot["out"] = copy.deepcopy(out)
 
+    def enter(section):
+        snapshot["section"] = section
+
     if world > 1 and not args.no_prove:
         # BASELINE config 4 at N GPUs: every commitment's point range is partitioned over the ranks
+        enter("plonk_prove")
         try:
             sec = real_prove_section(L, torch, dist, world)
         except Exception as e:  # never lose the headline line to the secondary measurement
             sec = {"error": repr(e)}
         keep("plonk_prove", sec)
+        enter("plonk_prove_hot_path")
         try:
             sec = prove_section(L, torch, dist, world, stream, beta)
         except Exception as e:
@@ -634,6 +697,7 @@ def main():
         keep("plonk_prove_hot_path", sec)
 
     if not args.no_prove:
+        enter("batch_prove")
         try:
             sec = real_batch_prove_section(L, torch, dist, world, rank)
         except Exception as e:
@@ -641,6 +705,7 @@ def main():
         keep("batch_prove", sec)
 
     if args.ultra_log_n:
+        enter("batch_prove_ultra")
         try:
             sec = batch_prove_section(L, torch, dist, world, rank, stream, args.ultra_log_n)
         except Exception as e:

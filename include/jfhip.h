@@ -48,6 +48,18 @@ typedef struct jfhip_stream jfhip_stream;  /* a HIP stream + its MSM/NTT workspa
  * current device.  Replaces nothing in the reference (ICICLE picks device 0 implicitly). */
 int32_t jfhip_init(int32_t device);
 
+/* Give back what the library holds on behalf of the calling thread and the process: the calling thread's default stream
+ * with its workspace, and the process-wide device-table caches (jfhip_cache_clear).  Handles the caller created
+ * (streams, SRS) stay valid and are the caller's to destroy.  The library can be used again afterwards.  No counterpart
+ * in the reference (ICICLE's RAII slices free themselves). */
+int32_t jfhip_shutdown(void);
+
+/* Free the process-wide caches of device tables (NTT twiddle tables per (domain size, direction, coset offset); the
+ * quotient kernel's 1/(n(x_i - 1)) table per (n, m, offset), 32 B x m each) that no call in flight is using.  The caches
+ * are bounded anyway (least recently used first, JFHIP_CACHE_BYTES per cache, default 8 GiB); a long-running prover that
+ * is done with a circuit size can give the memory back at once. */
+int32_t jfhip_cache_clear(void);
+
 /* Copy the calling thread's last error message (NUL-terminated, truncated to len). */
 int32_t jfhip_last_error(char *buf, size_t len);
 
@@ -59,6 +71,10 @@ int32_t jfhip_device_count(void);
  * per-thread default stream owned by the library. */
 int32_t jfhip_stream_create(jfhip_stream **out);
 int32_t jfhip_stream_destroy(jfhip_stream *s);
+/* Synchronise `s` (NULL: the calling thread's default stream) and free its grow-only MSM / NTT workspace (about 4.9 GiB
+ * after a 2^24-point MSM); the stream stays usable and grows a workspace again on demand.  The default stream of a
+ * thread other than the one that loaded the library is released with its workspace when that thread exits. */
+int32_t jfhip_stream_release_workspace(jfhip_stream *s);
 /* Replaces CudaStream::synchronize()  (pcs/src/univariate_kzg/mod.rs:942). */
 int32_t jfhip_stream_sync(jfhip_stream *s);
 /* The raw hipStream_t of a stream (for callers that enqueue their own HIP work). */

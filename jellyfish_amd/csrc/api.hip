@@ -4,14 +4,42 @@
 #include <stdarg.h>
 
 #include <functional>
+#include <thread>
 
 #include "common.hpp"
 
 namespace jf {
 
 static thread_local std::string t_err;
-static thread_local jfhip_stream* t_default_stream = nullptr;
 static bool g_profiling = false;
+
+static void stream_release(jfhip_stream* s);
+
+// The per-thread default stream (stream == NULL in the C ABI) and its workspace live as long as their thread: a rayon /
+// std::thread worker that exits gives its device memory back.  The thread that loaded the library is left alone: its
+// thread_local destructors run during process teardown, possibly after the HIP runtime has gone.
+static const std::thread::id g_loader_thread = std::this_thread::get_id();
+struct DefaultStreamHolder {
+    jfhip_stream* st = nullptr;
+    ~DefaultStreamHolder() {
+        if (st && std::this_thread::get_id() != g_loader_thread) {
+            (void)hipStreamSynchronize(st->s);
+            stream_release(st);
+            delete st;
+        }
+        st = nullptr;
+    }
+};
+static thread_local DefaultStreamHolder t_default;
+
+size_t cache_byte_cap() {
+    static const size_t cap = [] {
+        const char* e = getenv("JFHIP_CACHE_BYTES");
+        unsigned long long v = e ? strtoull(e, nullptr, 10) : 0ull;
+        return v ? (size_t)v : (size_t)8 << 30;
+    }();
+    return cap;
+}
 
 void set_error(const char* fmt, ...) {
     char buf[512];
@@ -78,19 +106,18 @@ void PhaseTimer::finish() {
 
 jfhip_stream* resolve_stream(jfhip_stream* s) {
     if (s) return s;
-    if (!t_default_stream) {
+    if (!t_default.st) {
         jfhip_stream* st = new jfhip_stream();
         if (hipStreamCreateWithFlags(&st->s, hipStreamNonBlocking) != hipSuccess) {
             delete st;
             return nullptr;
         }
         st->owned = true;
-        t_default_stream = st;
+        t_default.st = st;
     }
-    return t_default_stream;
+    return t_default.st;
 }
 
-static void stream_release(jfhip_stream* s);
 static void lanes_release(jfhip_stream* s) {
     for (int i = 0; i < jfhip_stream::MAX_LANES - 1; i++) {
         if (s->lane[i]) {
@@ -106,15 +133,23 @@ static void lanes_release(jfhip_stream* s) {
     s->fork_ev = nullptr;
 }
 
+static void workspace_release(jfhip_stream* s) {
+    for (int i = 0; i < jfhip_stream::MAX_LANES - 1; i++)
+        if (s->lane[i]) {
+            (void)hipStreamSynchronize(s->lane[i]->s);
+            workspace_release(s->lane[i]);
+        }
+    s->for_each_buf([](DevBuf* b) { b->release(); });
+}
+
 static void stream_release(jfhip_stream* s) {
     lanes_release(s);
-    DevBuf* bufs[] = {&s->scalars, &s->dig, &s->dig2, &s->midbase, &s->midcnt, &s->midcur, &s->finecnt, &s->finecur, &s->sorted, &s->counts, &s->offs,   &s->cursor, &s->bsum,
-                      &s->buckets, &s->partA, &s->partB, &s->red0,   &s->red1,   &s->result, &s->ntt_tmp,
-                      &s->ntt_io,  &s->poly_a, &s->poly_b, &s->poly_c, &s->quot_consts};
-    for (DevBuf* b : bufs) b->release();
+    s->for_each_buf([](DevBuf* b) { b->release(); });
     if (s->ev_ready)
         for (int i = 0; i <= MAX_PHASES; i++) (void)hipEventDestroy(s->ev[i]);
+    s->ev_ready = false;
     if (s->owned && s->s) (void)hipStreamDestroy(s->s);
+    s->s = nullptr;
 }
 
 static int fq_bytes(int32_t curve) { return fq_limbs32(curve) * 4; }
@@ -237,6 +272,31 @@ int32_t jfhip_stream_destroy(jfhip_stream* s) {
     stream_release(s);
     delete s;
     return JFHIP_OK;
+}
+
+int32_t jfhip_stream_release_workspace(jfhip_stream* s) {
+    JF_STREAM(st, s);
+    std::lock_guard<std::mutex> lk(st->mu);
+    JF_HIP(hipStreamSynchronize(st->s));
+    workspace_release(st);
+    return JFHIP_OK;
+}
+
+int32_t jfhip_cache_clear(void) {
+    ntt_cache_clear();
+    quotient_cache_clear();
+    return JFHIP_OK;
+}
+
+int32_t jfhip_shutdown(void) {
+    // the calling thread's default stream and the process-wide table caches; explicit handles stay the caller's
+    if (t_default.st) {
+        (void)hipStreamSynchronize(t_default.st->s);
+        stream_release(t_default.st);
+        delete t_default.st;
+        t_default.st = nullptr;
+    }
+    return jfhip_cache_clear();
 }
 
 int32_t jfhip_stream_sync(jfhip_stream* s) {
@@ -456,17 +516,25 @@ static int32_t msm_batch_locked(const jfhip_srs* srs, const size_t* lens, size_t
         JF_HIP(hipEventRecord(st->fork_ev, st->s));
         for (int i = 0; i < lanes - 1; i++) JF_HIP(hipStreamWaitEvent(st->lane[i]->s, st->fork_ev, 0));
     }
-    for (size_t b = 0; b < batch; b++) {
+    int32_t rc = JFHIP_OK;
+    for (size_t b = 0; b < batch && rc == JFHIP_OK; b++) {
         jfhip_stream* ls = (b % lanes == 0) ? st : st->lane[b % lanes - 1];
         const void* d_scalars = nullptr;
-        JF_TRY(stage(b, ls, &d_scalars));
-        JF_TRY(msm_device_locked(srs, 0, d_scalars, lens[b], d_res + b * rec, ls));
+        rc = stage(b, ls, &d_scalars);
+        if (rc == JFHIP_OK) rc = msm_device_locked(srs, 0, d_scalars, lens[b], d_res + b * rec, ls);
     }
+    // join the lanes whatever happened: the caller may release its buffers as soon as this returns an error, and
+    // the lanes may still be reading / writing them
     for (int i = 0; i < lanes - 1; i++) {
+        if (rc != JFHIP_OK) {
+            (void)hipStreamSynchronize(st->lane[i]->s);
+            continue;
+        }
         JF_HIP(hipEventRecord(st->join_ev[i], st->lane[i]->s));
         JF_HIP(hipStreamWaitEvent(st->s, st->join_ev[i], 0));
     }
-    return JFHIP_OK;
+    if (rc != JFHIP_OK) (void)hipStreamSynchronize(st->s);
+    return rc;
 }
 
 int32_t jfhip_msm_batch_device(const jfhip_srs* srs, const void* const* d_scalars, const size_t* lens, size_t batch,

@@ -6,6 +6,10 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <stdlib.h>
+
+#include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -43,6 +47,81 @@ struct DevBuf {
 
 constexpr int MAX_PHASES = 16;
 
+// A process-wide cache of device tables (NTT twiddle tables, quotient-domain inverses), bounded by bytes and evicted
+// least-recently-used.  get() hands out the value together with a Lease: while a Lease is alive the entry cannot be
+// evicted, so a caller keeps it until the kernels that read the tables are ENQUEUED (eviction frees with hipFree,
+// which waits for enqueued work).  Val needs: size_t bytes() const; void release().
+using Lease = std::shared_ptr<void>;
+size_t cache_byte_cap();   // JFHIP_CACHE_BYTES, default 8 GiB per cache
+
+template <class Key, class Val>
+struct DevCache {
+    struct Entry {
+        Val v;
+        uint64_t last = 0;
+        int pins = 0;
+    };
+    std::mutex mu;
+    std::map<Key, Entry> m;
+    uint64_t tick = 0;
+    size_t total = 0;
+
+    void unpin(const Key& k) {
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = m.find(k);
+        if (it != m.end() && it->second.pins > 0) it->second.pins--;
+    }
+    // evict unpinned entries, oldest first, until `need` more bytes fit under the cap (caller holds mu)
+    void make_room(size_t need) {
+        const size_t cap = cache_byte_cap();
+        while (total + need > cap) {
+            auto victim = m.end();
+            for (auto it = m.begin(); it != m.end(); ++it)
+                if (it->second.pins == 0 && (victim == m.end() || it->second.last < victim->second.last)) victim = it;
+            if (victim == m.end()) return;  // everything is in use: grow past the cap rather than fail
+            total -= victim->second.v.bytes();
+            victim->second.v.release();
+            m.erase(victim);
+        }
+    }
+    template <class Build>
+    int32_t get(const Key& k, Val* out, Lease* lease, size_t bytes_hint, Build build) {
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = m.find(k);
+        if (it == m.end()) {
+            make_room(bytes_hint);
+            Val v;
+            int32_t rc = build(&v);
+            if (rc != JFHIP_OK) {
+                v.release();  // partial allocations of a failed build
+                return rc;
+            }
+            Entry e;
+            e.v = v;
+            it = m.emplace(k, e).first;
+            total += v.bytes();
+        }
+        it->second.last = ++tick;
+        it->second.pins++;
+        *out = it->second.v;
+        *lease = Lease(nullptr, [this, k](void*) { this->unpin(k); });
+        return JFHIP_OK;
+    }
+    // free every entry that no call holds
+    void clear() {
+        std::lock_guard<std::mutex> lk(mu);
+        for (auto it = m.begin(); it != m.end();) {
+            if (it->second.pins == 0) {
+                total -= it->second.v.bytes();
+                it->second.v.release();
+                it = m.erase(it);
+            } else ++it;
+        }
+    }
+};
+void ntt_cache_clear();
+void quotient_cache_clear();
+
 }  // namespace jf
 
 struct jfhip_stream {
@@ -60,6 +139,14 @@ struct jfhip_stream {
     static constexpr int MAX_LANES = 3;
     jfhip_stream* lane[MAX_LANES - 1] = {};
     hipEvent_t fork_ev = nullptr, join_ev[MAX_LANES - 1] = {};
+    // every device buffer of the workspace (release, accounting): a new DevBuf member must be listed here only
+    template <class F>
+    void for_each_buf(F f) {
+        jf::DevBuf* all[] = {&scalars, &dig, &dig2, &sorted, &counts, &offs, &cursor, &bsum, &midbase, &midcnt, &midcur,
+                             &finecnt, &finecur, &buckets, &partA, &partB, &red0, &red1, &result, &raw29, &heavy,
+                             &ntt_tmp, &ntt_io, &poly_a, &poly_b, &poly_c, &quot_consts};
+        for (jf::DevBuf* b : all) f(b);
+    }
     // phase timing
     hipEvent_t ev[jf::MAX_PHASES + 1] = {};
     bool ev_ready = false;
@@ -104,7 +191,7 @@ int32_t srs_pack_points(int32_t curve, const uint8_t* d_raw, size_t n, size_t st
 int32_t ntt_device(int32_t curve, uint32_t* d_data, uint32_t log_n, size_t batch, int inverse,
                    const uint64_t* coset_mont, size_t in_len, jfhip_stream* st);
 int32_t ntt_root_tables(int32_t curve, uint32_t log_n, const uint32_t** lo, const uint32_t** hi, uint32_t* a,
-                        jfhip_stream* st);
+                        jfhip_stream* st, Lease* lease);
 int32_t plonk_quotient_turbo_device(int32_t curve, uint32_t log_n, uint32_t log_m, const uint32_t* sel,
                                     const uint32_t* sig, const uint32_t* wires, const uint32_t* zperm,
                                     const uint32_t* pi, const uint64_t* k_mont, const uint64_t* challenges_mont,

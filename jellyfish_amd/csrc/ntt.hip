@@ -37,6 +37,15 @@ struct NttTables {
     uint32_t* ch = nullptr;        // s0 * h^(i 2^a)
     uint32_t a = 0;
     int scale_mode = 0;  // 0 none, 1 constant n^-1, 2 two-level table
+    uint32_t nbytes = 0;
+    size_t bytes() const { return nbytes; }
+    void release() {
+        uint32_t** all[] = {&params, &tw_small, &tl, &th, &cl, &ch};
+        for (uint32_t** q : all) {
+            if (*q) (void)hipFree(*q);
+            *q = nullptr;
+        }
+    }
 };
 
 struct NttPass {
@@ -681,28 +690,30 @@ struct TableKey {
     uint64_t coset[4];
     bool operator<(const TableKey& o) const { return memcmp(this, &o, sizeof(TableKey)) < 0; }
 };
-static std::mutex g_tab_mu;
-static std::map<TableKey, NttTables> g_tables;
+static DevCache<TableKey, NttTables> g_tables;
+void ntt_cache_clear() { g_tables.clear(); }
 
 template <class Fr>
 static int32_t build_tables(uint32_t log_n, int inverse, const uint64_t* coset_mont, NttTables* out,
                             jfhip_stream* st) {
+    // allocations go straight into *out: on failure the cache releases whatever is already there
     constexpr int N = Fr::N;
-    NttTables t;
+    NttTables& t = *out;
     t.a = (log_n + 1) / 2;
     const uint32_t lo_n = 1u << t.a, hi_n = 1u << (log_n - t.a);
     const bool has_coset = coset_mont != nullptr;
     t.scale_mode = has_coset ? 2 : (inverse ? 1 : 0);
-    uint32_t* d_coset = nullptr;
+    t.nbytes = (uint32_t)((4 + 256 + (size_t)(has_coset ? 2 : 1) * (lo_n + hi_n)) * N * 4);
     JF_HIP(hipMalloc(&t.params, 4 * N * 4));
     JF_HIP(hipMalloc(&t.tw_small, 256 * N * 4));
     JF_HIP(hipMalloc(&t.tl, (size_t)lo_n * N * 4));
     JF_HIP(hipMalloc(&t.th, (size_t)hi_n * N * 4));
+    uint32_t* d_coset = nullptr;
     if (has_coset) {
-        JF_HIP(hipMalloc(&d_coset, N * 4));
-        JF_HIP(hipMemcpyAsync(d_coset, coset_mont, N * 4, hipMemcpyHostToDevice, st->s));
         JF_HIP(hipMalloc(&t.cl, (size_t)lo_n * N * 4));
         JF_HIP(hipMalloc(&t.ch, (size_t)hi_n * N * 4));
+        d_coset = t.cl;  // the offset is staged in the first slot of its own power table, which the kernels below fill last
+        JF_HIP(hipMemcpyAsync(d_coset, coset_mont, N * 4, hipMemcpyHostToDevice, st->s));
     }
     hipLaunchKernelGGL((k_ntt_params<Fr>), dim3(1), dim3(64), 0, st->s, log_n, inverse, d_coset, (int)has_coset,
                        t.params);
@@ -713,22 +724,20 @@ static int32_t build_tables(uint32_t log_n, int inverse, const uint64_t* coset_m
     hipLaunchKernelGGL((k_pow_table<Fr>), dim3((hi_n + 255) / 256), dim3(256), 0, st->s, t.params,
                        (const uint32_t*)nullptr, (uint64_t)lo_n, hi_n, t.th);
     if (has_coset) {
-        hipLaunchKernelGGL((k_pow_table<Fr>), dim3((lo_n + 255) / 256), dim3(256), 0, st->s, t.params + 3 * N,
-                           (const uint32_t*)nullptr, (uint64_t)1, lo_n, t.cl);
         hipLaunchKernelGGL((k_pow_table<Fr>), dim3((hi_n + 255) / 256), dim3(256), 0, st->s, t.params + 3 * N,
                            inverse ? t.params + 2 * N : (const uint32_t*)nullptr, (uint64_t)lo_n, hi_n, t.ch);
+        hipLaunchKernelGGL((k_pow_table<Fr>), dim3((lo_n + 255) / 256), dim3(256), 0, st->s, t.params + 3 * N,
+                           (const uint32_t*)nullptr, (uint64_t)1, lo_n, t.cl);
     }
     JF_HIP(hipGetLastError());
     JF_HIP(hipStreamSynchronize(st->s));
-    if (d_coset) JF_HIP(hipFree(d_coset));
-    *out = t;
     return JFHIP_OK;
 }
 
-// cached per (device, curve, log_n, direction, coset)
+// cached per (device, curve, log_n, direction, coset), bounded (DevCache)
 template <class Fr>
 static int32_t get_tables(int32_t curve, uint32_t log_n, int inverse, const uint64_t* coset_mont, NttTables* out,
-                          jfhip_stream* st) {
+                          jfhip_stream* st, Lease* lease) {
     TableKey key;
     memset(&key, 0, sizeof(key));
     JF_HIP(hipGetDevice(&key.device));
@@ -737,21 +746,17 @@ static int32_t get_tables(int32_t curve, uint32_t log_n, int inverse, const uint
     key.has_coset = coset_mont ? 1 : 0;
     key.log_n = log_n;
     if (coset_mont) memcpy(key.coset, coset_mont, 32);
-    std::lock_guard<std::mutex> lk(g_tab_mu);
-    auto it = g_tables.find(key);
-    if (it == g_tables.end()) {
-        JF_TRY(build_tables<Fr>(log_n, inverse ? 1 : 0, coset_mont, out, st));
-        g_tables[key] = *out;
-    } else *out = it->second;
-    return JFHIP_OK;
+    const size_t hint = ((size_t)4 << ((log_n + 1) / 2)) * Fr::N * 4;
+    return g_tables.get(key, out, lease, hint,
+                        [&](NttTables* t) { return build_tables<Fr>(log_n, inverse ? 1 : 0, coset_mont, t, st); });
 }
 
 // two-level table of the forward domain generator: w^e = lo[e mod 2^a] * hi[e >> a]
 int32_t ntt_root_tables(int32_t curve, uint32_t log_n, const uint32_t** lo, const uint32_t** hi, uint32_t* a,
-                        jfhip_stream* st) {
+                        jfhip_stream* st, Lease* lease) {
     NttTables t;
-    if (curve == JFHIP_BN254) JF_TRY(get_tables<Bn254Fr>(curve, log_n, 0, nullptr, &t, st));
-    else JF_TRY(get_tables<Bls381Fr>(curve, log_n, 0, nullptr, &t, st));
+    if (curve == JFHIP_BN254) JF_TRY(get_tables<Bn254Fr>(curve, log_n, 0, nullptr, &t, st, lease));
+    else JF_TRY(get_tables<Bls381Fr>(curve, log_n, 0, nullptr, &t, st, lease));
     *lo = t.tl;
     *hi = t.th;
     *a = t.a;
@@ -788,7 +793,8 @@ static int32_t ntt_device_t(int32_t curve, uint32_t* d_data, uint32_t log_n, siz
     }
     PhaseTimer pt(st, 1);
     NttTables tabs;
-    JF_TRY(get_tables<Fr>(curve, log_n, inverse ? 1 : 0, coset_mont, &tabs, st));
+    Lease lease;  // keeps the tables resident until every pass below is enqueued
+    JF_TRY(get_tables<Fr>(curve, log_n, inverse ? 1 : 0, coset_mont, &tabs, st, &lease));
     // digit plan
     uint32_t ndig = (log_n + NTT_MAX_DIGIT - 1) / NTT_MAX_DIGIT;
     uint32_t dig[4] = {0, 0, 0, 0};

@@ -23,15 +23,23 @@ constexpr int QUOT_NW = 5;
 struct QuotDomain {
     uint32_t* inv_den = nullptr;  // 1 / (n (g w^i - 1)), i < m
     uint32_t* zh_inv = nullptr;   // 1 / ((g w^i)^n - 1), i < ratio
+    size_t nbytes = 0;
+    size_t bytes() const { return nbytes; }
+    void release() {
+        if (inv_den) (void)hipFree(inv_den);
+        if (zh_inv) (void)hipFree(zh_inv);
+        inv_den = zh_inv = nullptr;
+    }
 };
 struct QuotKey {
     int device, curve;
     uint32_t log_n, log_m;
-    uint32_t offset[8];  // coset offset (Montgomery limbs); all zero = Fr::GENERATOR
+    uint32_t builtin_gen;  // Fr::GENERATOR as a small integer when no explicit offset was given, else 0
+    uint32_t offset[8];    // explicit coset offset (Montgomery limbs)
     bool operator<(const QuotKey& o) const { return memcmp(this, &o, sizeof(QuotKey)) < 0; }
 };
-static std::mutex g_q_mu;
-static std::map<QuotKey, QuotDomain> g_qdom;
+static DevCache<QuotKey, QuotDomain> g_qdom;
+void quotient_cache_clear() { g_qdom.clear(); }
 
 template <class Fr>
 JF_DEV Fp<Fr> root_pow(const uint32_t* __restrict__ lo, const uint32_t* __restrict__ hi, uint32_t a, uint64_t e) {
@@ -277,9 +285,18 @@ static int32_t quotient_t(int32_t curve, int nw, uint32_t log_n, uint32_t log_m,
         set_error("quotient: domain size ratio %u unsupported", ratio);
         return JFHIP_ERR_INVALID;
     }
+    if (offset_mont) {
+        bool zero = true;
+        for (int i = 0; i < 4; i++) zero = zero && offset_mont[i] == 0;
+        if (zero) {
+            set_error("quotient: coset offset 0 is not a coset");
+            return JFHIP_ERR_INVALID;
+        }
+    }
     const uint32_t *lo, *hi;
     uint32_t a;
-    JF_TRY(ntt_root_tables(curve, log_m, &lo, &hi, &a, st));
+    Lease root_lease, dom_lease;  // held until the kernels below are enqueued
+    JF_TRY(ntt_root_tables(curve, log_m, &lo, &hi, &a, st, &root_lease));
     QuotDomain qd;
     {
         QuotKey key;
@@ -288,21 +305,21 @@ static int32_t quotient_t(int32_t curve, int nw, uint32_t log_n, uint32_t log_m,
         key.curve = curve;
         key.log_n = log_n;
         key.log_m = log_m;
+        key.builtin_gen = gen.gen;
         memcpy(key.offset, gen.v, 32);
-        std::lock_guard<std::mutex> lk(g_q_mu);
-        auto it = g_qdom.find(key);
-        if (it == g_qdom.end()) {
-            JF_HIP(hipMalloc(&qd.inv_den, m * N * 4));
-            JF_HIP(hipMalloc(&qd.zh_inv, (size_t)ratio * N * 4));
+        JF_TRY(g_qdom.get(key, &qd, &dom_lease, m * N * 4, [&](QuotDomain* q) -> int32_t {
+            q->nbytes = (m + ratio) * N * 4;
+            JF_HIP(hipMalloc(&q->inv_den, m * N * 4));
+            JF_HIP(hipMalloc(&q->zh_inv, (size_t)ratio * N * 4));
             const uint64_t lanes = (m + INV_CHUNK - 1) / INV_CHUNK;
             hipLaunchKernelGGL((k_quot_inv_den<Fr>), dim3((unsigned)((lanes + 127) / 128)), dim3(128), 0, st->s, lo,
-                               hi, a, log_n, log_m, gen, qd.inv_den);
+                               hi, a, log_n, log_m, gen, q->inv_den);
             hipLaunchKernelGGL((k_quot_zh_inv<Fr>), dim3(1), dim3(64), 0, st->s, lo, hi, a, log_n, ratio, gen,
-                               qd.zh_inv);
+                               q->zh_inv);
             JF_HIP(hipGetLastError());
             JF_HIP(hipStreamSynchronize(st->s));
-            g_qdom[key] = qd;
-        } else qd = it->second;
+            return JFHIP_OK;
+        }));
     }
     // host -> device: k[6] (padded), alpha, beta, gamma, tau, alpha_base
     JF_TRY(st->quot_consts.ensure((QUOT_NIN + QC_COUNT) * N * 4));

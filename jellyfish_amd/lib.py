@@ -31,7 +31,7 @@ def library_path() -> str:
 
 # every symbol include/jfhip.h declares
 SYMBOLS = [
-    "jfhip_init", "jfhip_last_error", "jfhip_device_count", "jfhip_stream_create", "jfhip_stream_destroy",
+    "jfhip_init", "jfhip_shutdown", "jfhip_cache_clear", "jfhip_stream_release_workspace", "jfhip_last_error", "jfhip_device_count", "jfhip_stream_create", "jfhip_stream_destroy",
     "jfhip_stream_sync", "jfhip_stream_raw", "jfhip_stream_wrap", "jfhip_srs_load", "jfhip_srs_load_device",
     "jfhip_srs_gen_for_testing", "jfhip_srs_free", "jfhip_srs_len", "jfhip_srs_window_bits", "jfhip_srs_read",
     "jfhip_msm", "jfhip_msm_batch", "jfhip_msm_batch_device", "jfhip_msm_device", "jfhip_msm_partial_device", "jfhip_g1_sum_partials",
@@ -94,6 +94,14 @@ def init(device: int = -1):
     _check(load_library().jfhip_init(device))
 
 
+def shutdown():
+    _check(load_library().jfhip_shutdown())
+
+
+def cache_clear():
+    _check(load_library().jfhip_cache_clear())
+
+
 def device_count() -> int:
     return load_library().jfhip_device_count()
 
@@ -111,6 +119,9 @@ class Stream:
 
     def sync(self):
         _check(load_library().jfhip_stream_sync(self.h))
+
+    def release_workspace(self):
+        _check(load_library().jfhip_stream_release_workspace(self.h))
 
     @property
     def raw(self) -> int:
