@@ -935,7 +935,7 @@ int32_t jfhip_witness_gather_device(const void* d_witness, size_t num_vars, cons
 // ---- field / group test surface ---------------------------------------------------------------------
 
 int32_t jfhip_field_op(int32_t field_id, int32_t op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
-    if (field_id < 0 || field_id > 3 || op < 0 || op > 10) {
+    if (field_id < 0 || field_id > 3 || op < 0 || op > 11) {
         set_error("bad field id / op");
         return JFHIP_ERR_INVALID;
     }

@@ -10,6 +10,8 @@
 // This form is INTERNAL to kernels (SRS window table, bucket accumulators): data crossing the C ABI stays in arkworks'
 // saturated Montgomery form with R = 2^(32 N); f29_from_fp / f29_to_fp convert (a few doublings / halvings: R'/R = 2^k).
 #pragma once
+#include <utility>
+
 #include "fp.hpp"
 
 namespace jf {
@@ -152,7 +154,10 @@ JF_HD bool f29_mulout_is_zero(const F29<C>& a) {
     return z == 0 || e == 0;
 }
 
-// re-slice 32-bit words holding a fully reduced value into 29-bit limbs (no Montgomery change)
+// re-slice 32-bit words holding a fully reduced value into 29-bit limbs (no Montgomery change).  On the device every
+// limb is one v_alignbit_b32 / shift + one mask on 32-bit registers: written with 64-bit shifts the compiler wants the two
+// source words in an aligned register pair and, for words that come straight from memory, fetches them a second time
+// with an overlapping load (8 loads and 24 registers for a 64-byte table point instead of 4 and 16).
 template <class C>
 JF_HD F29<C> f29_unpack_bits(const Fp<C>& x) {
     constexpr int L = F29<C>::L;
@@ -160,9 +165,19 @@ JF_HD F29<C> f29_unpack_bits(const Fp<C>& x) {
 #pragma unroll
     for (int i = 0; i < L; i++) {
         const int bit = 29 * i, w = bit / 32, s = bit % 32;
-        uint64_t lo = w < C::N ? x.v[w] : 0u;
-        uint64_t hi = (w + 1) < C::N ? x.v[w + 1] : 0u;
-        r.v[i] = (uint32_t)(((lo | (hi << 32)) >> s) & F29Params<C>::MASK);
+        const uint32_t lo = w < C::N ? x.v[w] : 0u;
+        const uint32_t hi = (w + 1) < C::N ? x.v[w + 1] : 0u;
+        uint32_t t;
+        if (s == 0) t = lo;
+        else if (s + 29 <= 32 || (w + 1) >= C::N) t = lo >> s;
+        else {
+#if defined(__HIP_DEVICE_COMPILE__)
+            t = __builtin_amdgcn_alignbit(hi, lo, s);
+#else
+            t = (lo >> s) | (hi << (32 - s));
+#endif
+        }
+        r.v[i] = t & F29Params<C>::MASK;
     }
     return r;
 }
@@ -249,9 +264,166 @@ JF_DEV F29<C> f29_mul(const F29<C>& a, const F29<C>& b) {
     r.v[L - 1] = (uint32_t)acc;
     return r;
 }
+// ---- grouped multiply-adds ------------------------------------------------------------------------------
+// N multiply-adds of one column in ONE asm statement.  Between two asm statements that hand a register on, the
+// compiler's hazard recogniser (it cannot see inside) puts an s_nop; one statement per multiply-add measured 6 % slower
+// in the bucket accumulation than statements of up to eight.
+JF_DEV void f29_mad_vv(uint64_t& acc, uint32_t x0, uint32_t y0) {
+    asm(JF_MAD29_TXT(1, 2) : "+v"(acc) : "v"(x0), "v"(y0) : "vcc");
+}
+JF_DEV void f29_mad_vv(uint64_t& acc, uint32_t x0, uint32_t x1, uint32_t y0, uint32_t y1) {
+    asm(JF_MAD29_TXT(1, 3) JF_MAD29_TXT(2, 4) : "+v"(acc) : "v"(x0), "v"(x1), "v"(y0), "v"(y1) : "vcc");
+}
+JF_DEV void f29_mad_vv(uint64_t& acc, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t y0, uint32_t y1,
+                       uint32_t y2, uint32_t y3) {
+    asm(JF_MAD29_TXT(1, 5) JF_MAD29_TXT(2, 6) JF_MAD29_TXT(3, 7) JF_MAD29_TXT(4, 8)
+        : "+v"(acc)
+        : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(y0), "v"(y1), "v"(y2), "v"(y3)
+        : "vcc");
+}
+JF_DEV void f29_mad_vv(uint64_t& acc, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t x4, uint32_t x5,
+                       uint32_t x6, uint32_t x7, uint32_t y0, uint32_t y1, uint32_t y2, uint32_t y3, uint32_t y4,
+                       uint32_t y5, uint32_t y6, uint32_t y7) {
+    asm(JF_MAD29_TXT(1, 9) JF_MAD29_TXT(2, 10) JF_MAD29_TXT(3, 11) JF_MAD29_TXT(4, 12) JF_MAD29_TXT(5, 13)
+            JF_MAD29_TXT(6, 14) JF_MAD29_TXT(7, 15) JF_MAD29_TXT(8, 16)
+        : "+v"(acc)
+        : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(x4), "v"(x5), "v"(x6), "v"(x7), "v"(y0), "v"(y1), "v"(y2), "v"(y3),
+          "v"(y4), "v"(y5), "v"(y6), "v"(y7)
+        : "vcc");
+}
+// the same with uniform second factors (limbs of p: compile-time constants, SGPRs)
+JF_DEV void f29_mad_vs(uint64_t& acc, uint32_t x0, uint32_t y0) {
+    asm(JF_MAD29_TXT(1, 2) : "+v"(acc) : "v"(x0), "s"(y0) : "vcc");
+}
+JF_DEV void f29_mad_vs(uint64_t& acc, uint32_t x0, uint32_t x1, uint32_t y0, uint32_t y1) {
+    asm(JF_MAD29_TXT(1, 3) JF_MAD29_TXT(2, 4) : "+v"(acc) : "v"(x0), "v"(x1), "s"(y0), "s"(y1) : "vcc");
+}
+JF_DEV void f29_mad_vs(uint64_t& acc, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t y0, uint32_t y1,
+                       uint32_t y2, uint32_t y3) {
+    asm(JF_MAD29_TXT(1, 5) JF_MAD29_TXT(2, 6) JF_MAD29_TXT(3, 7) JF_MAD29_TXT(4, 8)
+        : "+v"(acc)
+        : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "s"(y0), "s"(y1), "s"(y2), "s"(y3)
+        : "vcc");
+}
+JF_DEV void f29_mad_vs(uint64_t& acc, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t x4, uint32_t x5,
+                       uint32_t x6, uint32_t x7, uint32_t y0, uint32_t y1, uint32_t y2, uint32_t y3, uint32_t y4,
+                       uint32_t y5, uint32_t y6, uint32_t y7) {
+    asm(JF_MAD29_TXT(1, 9) JF_MAD29_TXT(2, 10) JF_MAD29_TXT(3, 11) JF_MAD29_TXT(4, 12) JF_MAD29_TXT(5, 13)
+            JF_MAD29_TXT(6, 14) JF_MAD29_TXT(7, 15) JF_MAD29_TXT(8, 16)
+        : "+v"(acc)
+        : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(x4), "v"(x5), "v"(x6), "v"(x7), "s"(y0), "s"(y1), "s"(y2), "s"(y3),
+          "s"(y4), "s"(y5), "s"(y6), "s"(y7)
+        : "vcc");
+}
+// acc += sum over k in [0, CNT) of X(K0 + k) * Y(K0 + k), in statements of 8 / 4 / 2 / 1; X, Y: functors int -> uint32_t
+template <int K0, int... K, class FX, class FY>
+JF_DEV void f29_mad_seq_vv(uint64_t& acc, FX X, FY Y, std::integer_sequence<int, K...>) {
+    f29_mad_vv(acc, X(std::integral_constant<int, K0 + K>{})..., Y(std::integral_constant<int, K0 + K>{})...);
+}
+template <int K0, int... K, class FX, class FY>
+JF_DEV void f29_mad_seq_vs(uint64_t& acc, FX X, FY Y, std::integer_sequence<int, K...>) {
+    f29_mad_vs(acc, X(std::integral_constant<int, K0 + K>{})..., Y(std::integral_constant<int, K0 + K>{})...);
+}
+template <bool UNIFORM, int K0, int CNT, class FX, class FY>
+JF_DEV void f29_mad_run(uint64_t& acc, FX X, FY Y) {
+    if constexpr (CNT > 0) {
+        constexpr int step = CNT >= 8 ? 8 : CNT >= 4 ? 4 : CNT >= 2 ? 2 : 1;
+        if constexpr (UNIFORM) f29_mad_seq_vs<K0>(acc, X, Y, std::make_integer_sequence<int, step>{});
+        else f29_mad_seq_vv<K0>(acc, X, Y, std::make_integer_sequence<int, step>{});
+        f29_mad_run<UNIFORM, K0 + step, CNT - step>(acc, X, Y);
+    }
+}
+// column I of the reduction: m[J] p[I - J], J in [J0, JEND)
+template <class C, int I, int J0, int JEND>
+JF_DEV void f29_col_mp(uint64_t& acc, const uint32_t* m) {
+    f29_mad_run<true, J0, JEND - J0>(
+        acc, [&](auto k) { return m[decltype(k)::value]; },
+        [&](auto k) { return F29Params<C>::P(I - decltype(k)::value); });
+}
+
+// a^2: the cross products a[J] a[I - J], J != I - J, come in equal pairs, so one multiply-add with the doubled operand
+// d = 2 a (limbs < 2^30) covers two of them: 45 + 81 multiply-adds for L = 9 instead of 81 + 81
+template <class C, int I>
+JF_DEV void f29_sqr_col_ab(uint64_t& acc, const uint32_t* a, const uint32_t* d) {
+    constexpr int L = F29Params<C>::L;
+    constexpr int J0 = I < L ? 0 : I - L + 1;
+    constexpr int JE = I / 2 + 1;   // J <= I - J
+    f29_mad_run<false, J0, JE - J0>(
+        acc, [&](auto k) { return a[decltype(k)::value]; },
+        [&](auto k) {
+            constexpr int J = decltype(k)::value;
+            return J < I - J ? d[I - J] : a[J];
+        });
+}
+template <class C, int I>
+JF_DEV void f29_sqr_cols(uint64_t& acc, const uint32_t* a, const uint32_t* d, uint32_t* m, uint32_t* r) {
+    using PP = F29Params<C>;
+    constexpr int L = PP::L;
+    if constexpr (I < L) {
+        f29_sqr_col_ab<C, I>(acc, a, d);
+        f29_col_mp<C, I, 0, I>(acc, m);
+        m[I] = ((uint32_t)acc * PP::INV) & PP::MASK;
+        f29_mad_s(acc, m[I], PP::P(0));
+        acc >>= 29;
+        f29_sqr_cols<C, I + 1>(acc, a, d, m, r);
+    } else if constexpr (I < 2 * L - 1) {
+        f29_sqr_col_ab<C, I>(acc, a, d);
+        f29_col_mp<C, I, I - L + 1, L>(acc, m);
+        r[I - L] = (uint32_t)acc & PP::MASK;
+        acc >>= 29;
+        f29_sqr_cols<C, I + 1>(acc, a, d, m, r);
+    }
+}
+// Input: normalised limbs < 2^29 (the doubled copy is the operand with limbs < 2^30).
 template <class C>
 JF_DEV F29<C> f29_sqr(const F29<C>& a) {
-    return f29_mul<C>(a, a);
+    constexpr int L = F29<C>::L;
+    uint32_t m[L], d[L];
+#pragma unroll
+    for (int i = 0; i < L; i++) d[i] = a.v[i] << 1;
+    F29<C> r;
+    uint64_t acc = 0;
+    f29_sqr_cols<C, 0>(acc, a.v, d, m, r.v);
+    r.v[L - 1] = (uint32_t)acc;
+    return r;
+}
+
+// a1 b1 + a2 b2 with ONE Montgomery reduction (3 L^2 multiply-adds instead of 4 L^2).  Limbs: all four operands
+// normalised (< 2^29), a column then holds at most 2 L products < 2^58 plus L of m p: < 2^63.3 for L <= 14.
+// Output: normalised limbs, value < (a1 b1 + a2 b2) / R' + p.
+template <class C, int I>
+JF_DEV void f29_dot2_cols(uint64_t& acc, const uint32_t* a1, const uint32_t* b1, const uint32_t* a2, const uint32_t* b2,
+                          uint32_t* m, uint32_t* r) {
+    using PP = F29Params<C>;
+    constexpr int L = PP::L;
+    constexpr int J0 = I < L ? 0 : I - L + 1;
+    constexpr int JE = I < L ? I + 1 : L;
+    if constexpr (I < 2 * L - 1) {
+        f29_mad_run<false, J0, JE - J0>(
+            acc, [&](auto k) { return a1[decltype(k)::value]; }, [&](auto k) { return b1[I - decltype(k)::value]; });
+        f29_mad_run<false, J0, JE - J0>(
+            acc, [&](auto k) { return a2[decltype(k)::value]; }, [&](auto k) { return b2[I - decltype(k)::value]; });
+        if constexpr (I < L) {
+            f29_col_mp<C, I, 0, I>(acc, m);
+            m[I] = ((uint32_t)acc * PP::INV) & PP::MASK;
+            f29_mad_s(acc, m[I], PP::P(0));
+        } else {
+            f29_col_mp<C, I, I - L + 1, L>(acc, m);
+            r[I - L] = (uint32_t)acc & PP::MASK;
+        }
+        acc >>= 29;
+        f29_dot2_cols<C, I + 1>(acc, a1, b1, a2, b2, m, r);
+    }
+}
+template <class C>
+JF_DEV F29<C> f29_dot2(const F29<C>& a1, const F29<C>& b1, const F29<C>& a2, const F29<C>& b2) {
+    constexpr int L = F29<C>::L;
+    uint32_t m[L];
+    F29<C> r;
+    uint64_t acc = 0;
+    f29_dot2_cols<C, 0>(acc, a1.v, b1.v, a2.v, b2.v, m, r.v);
+    r.v[L - 1] = (uint32_t)acc;
+    return r;
 }
 #else
 template <class C>
@@ -282,6 +454,31 @@ JF_HD F29<C> f29_mul(const F29<C>& a, const F29<C>& b) {
 template <class C>
 JF_HD F29<C> f29_sqr(const F29<C>& a) {
     return f29_mul<C>(a, a);
+}
+template <class C>
+JF_HD F29<C> f29_dot2(const F29<C>& a1, const F29<C>& b1, const F29<C>& a2, const F29<C>& b2) {
+    constexpr int L = F29<C>::L;
+    using PP = F29Params<C>;
+    uint32_t m[L];
+    F29<C> r;
+    uint64_t acc = 0;
+    for (int k = 0; k < L; k++) {
+        for (int i = 0; i <= k; i++) acc += (uint64_t)a1.v[i] * b1.v[k - i] + (uint64_t)a2.v[i] * b2.v[k - i];
+        for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * PP::P(k - i);
+        m[k] = ((uint32_t)acc * PP::INV) & PP::MASK;
+        acc += (uint64_t)m[k] * PP::P(0);
+        acc >>= 29;
+    }
+    for (int k = L; k < 2 * L - 1; k++) {
+        for (int i = k - L + 1; i < L; i++) {
+            acc += (uint64_t)a1.v[i] * b1.v[k - i] + (uint64_t)a2.v[i] * b2.v[k - i];
+            acc += (uint64_t)m[i] * PP::P(k - i);
+        }
+        r.v[k - L] = (uint32_t)acc & PP::MASK;
+        acc >>= 29;
+    }
+    r.v[L - 1] = (uint32_t)acc;
+    return r;
 }
 #endif
 

@@ -444,13 +444,16 @@ struct Rare29 {
     XYZZ29<Cv> acc;
     bool inf;
 };
+// The point comes in as its table address and sign, not as the limbs the hot loop holds: those then die right after
+// their product instead of staying live (18 registers) until the P == 0 test.
 template <class Cv>
-JF_COLD Rare29<Cv> xyzz29_add_rare(XYZZ29<Cv> acc, F29<typename Cv::Fq> x2, F29<typename Cv::Fq> y2) {
+JF_COLD Rare29<Cv> xyzz29_add_rare(XYZZ29<Cv> acc, const uint32_t* __restrict__ table_point, bool negate) {
     using Q = typename Cv::Fq;
     XYZZ<Cv> a = xyzz29_to_std<Cv>(acc, false);
-    Affine<Cv> q;
-    q.x = f29_to_fp<Q>(x2);
-    q.y = f29_to_fp<Q>(y2);
+    Affine<Cv> q = affine_load<Cv>(table_point);   // bits of (x R', y R')
+    q.x = f29_to_fp<Q>(f29_unpack_bits<Q>(q.x));
+    q.y = f29_to_fp<Q>(f29_unpack_bits<Q>(q.y));
+    if (negate) q.y = fp_neg<Q>(q.y);
     xyzz_add_affine<Cv>(a, q);
     Rare29<Cv> r;
     r.inf = a.is_inf();
@@ -496,6 +499,9 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
         b_hi = off[b + 1];
     }
 
+    // end of the FOLLOWING bucket, fetched one run ahead: the hand-over to the next bucket then needs no load it has to
+    // wait for (off has B + 1 entries; b + 1 == B only for the last bucket, whose successor is never entered)
+    uint32_t nx_hi = off[b + 2 <= B ? b + 2 : B];
     XYZZ29<Cv> acc;
     bool inf = true;
     uint32_t run_start = start;
@@ -520,22 +526,57 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     };
 
     // software pipeline: the table point of entry pos + 1 (a random 64 / 96-byte gather from a multi-GiB table) and the
-    // sorted entry pos + 2 are in flight while entry pos is added
+    // sorted entry pos + 2 are in flight while entry pos is added.  Order matters: vmcnt retires in order, so the bucket
+    // hand-over (dependent loads on off[], waited for at once) comes BEFORE the gather is issued -- after it, every such
+    // wait also waited for the gather (half of all iterations have some lane at a bucket boundary).  The gathered words
+    // pass through an empty asm at the bottom of the iteration, their only use: with the uses visible the compiler
+    // re-fetches words it wants as register pairs with overlapping loads (7 loads, 22 registers for 64 bytes).
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int NV = PT / 4;
+    auto gather = [&](uint32_t e, u32x4* dst) {
+        const u32x4* src = reinterpret_cast<const u32x4*>(table + (size_t)(e & 0x7fffffffu) * PT);
+#pragma unroll
+        for (int k = 0; k < NV; k++) dst[k] = src[k];
+    };
     uint32_t e_cur = sorted[start];
     uint32_t e_nxt = (start + 1 < end) ? sorted[start + 1] : e_cur;
-    Affine<Cv> p_cur = affine_load<Cv>(table + (size_t)(e_cur & 0x7fffffffu) * PT);
+    u32x4 cur[NV], nxt[NV];
+    gather(e_cur, cur);
     for (uint32_t pos = start; pos < end; pos++) {
-        const Affine<Cv> p_nxt = affine_load<Cv>(table + (size_t)(e_nxt & 0x7fffffffu) * PT);
-        const uint32_t e_nx2 = (pos + 2 < end) ? sorted[pos + 2] : e_nxt;
         if (pos >= b_hi) {
             flush(pos);
             inf = true;
             run_start = pos;
-            next_bucket(off, B, pos, b, b_lo, b_hi);
+            b++;
+            b_lo = b_hi;
+            b_hi = nx_hi;
+            if (pos >= b_hi) {   // empty buckets follow: binary search for the one holding pos (see next_bucket)
+                uint32_t slo = b + 1, shi = B;
+                while (shi - slo > 1) {
+                    uint32_t mid = (slo + shi) >> 1;
+                    if (off[mid] <= pos) slo = mid;
+                    else shi = mid;
+                }
+                b = slo;
+                b_lo = off[b];
+                b_hi = off[b + 1];
+            }
+            nx_hi = off[b + 2 <= B ? b + 2 : B];
         }
+        gather(e_nxt, nxt);
+        const uint32_t e_nx2 = (pos + 2 < end) ? sorted[pos + 2] : e_nxt;
         do {
             const uint32_t e = e_cur;
-            const Affine<Cv> p = p_cur;
+            Affine<Cv> p;
+#pragma unroll
+            for (int k = 0; k < NV; k++) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int w = 4 * k + j;
+                    if (w < Q::N) p.x.v[w] = cur[k][j];
+                    else p.y.v[w - Q::N] = cur[k][j];
+                }
+            }
             if (p.is_inf()) break;
             F x2 = f29_unpack_bits<Q>(p.x);
             F y2 = f29_unpack_bits<Q>(p.y);
@@ -554,7 +595,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
             F PP = f29_sqr<Q>(P);
             if (f29_mulout_is_zero<Q>(PP)) {
                 XYZZ29<Cv> ac = acc;
-                Rare29<Cv> rr = xyzz29_add_rare<Cv>(ac, x2, y2);
+                Rare29<Cv> rr = xyzz29_add_rare<Cv>(ac, table + (size_t)(e & 0x7fffffffu) * PT, (e >> 31) != 0);
                 acc = rr.acc;
                 inf = rr.inf;
                 break;
@@ -563,14 +604,20 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
             F PPP = f29_mul<Q>(P, PP);
             F Qv = f29_mul<Q>(acc.X, PP);
             F X3 = f29_sub3<Q, 6>(f29_sqr<Q>(R), PPP, Qv, Qv);
-            F Y3 = f29_sub<Q, 2>(f29_mul<Q>(R, f29_sub<Q, 8>(Qv, X3)), f29_mul<Q>(acc.Y, PPP));
+            // Y3 = R (Q - X3) - Y PPP as ONE reduction: R (Q - X3 + 8p) + (4p - Y) PPP < (5.66 * 9.66 + 4 * 1.66) p^2 / R' + p
+            // < 1.37 p (p / R' < 1 / 168 for every supported field)
+            F Y3 = f29_dot2<Q>(R, f29_sub<Q, 8>(Qv, X3), f29_sub<Q, 4>(zero29, acc.Y), PPP);
             acc.X = X3;
             acc.Y = Y3;
             acc.ZZ = f29_mul<Q>(acc.ZZ, PP);
             acc.ZZZ = f29_mul<Q>(acc.ZZZ, PPP);
         } while (0);
+#pragma unroll
+        for (int k = 0; k < NV; k++) {
+            asm volatile("" : "+v"(nxt[k]));
+            cur[k] = nxt[k];
+        }
         e_cur = e_nxt;
-        p_cur = p_nxt;
         e_nxt = e_nx2;
     }
     flush(end);
@@ -970,17 +1017,17 @@ static int32_t srs_build_table_t(jfhip_srs* srs, jfhip_stream* st) {
     return JFHIP_OK;
 }
 
-// Which arithmetic the bucket accumulation of an SRS uses.  Measured on MI355X (BN254, uniform scalars): the 29-bit-limb
-// kernel is 17 % faster at 2^20 points (1.33 vs 1.60 ms) and 13 % slower at 2^24 (20.7 vs 18.3 ms; 12 GiB table, 49 % of
-// a wave's iterations cross a bucket boundary); in between: 2^22 points 4.74 vs 5.29 ms, 2^23 points 11.4 vs 10.9 ms.
-// So the default takes it up to 2^22 points (+ the few extra SRS elements a circuit of that size needs).  BLS12-381
-// (14 limbs of 29 bits) is never faster than its saturated kernel (2^18: 0.94 vs 0.85 ms, 2^21: 6.1 vs 5.5, 2^22: 12.2
-// vs 11.0) and stays saturated.  JFHIP_MSM_F29=0 / 1 forces saturated / 29-bit limbs (A/B measurements).
+// Which arithmetic the bucket accumulation of an SRS uses.  Measured on MI355X (uniform scalars), bucket_accumulate phase,
+// 29-bit limbs vs saturated: BN254 2^20 points 1.24 vs 1.59 ms, 2^22 4.24 vs 5.29, 2^24 14.9 vs 18.3 -- the 29-bit kernel
+// everywhere (profiles/r02_*; before the gather of its software pipeline was moved behind the bucket hand-over it LOST at
+// 2^24, 20.7 ms).  BLS12-381 (14 limbs of 29 bits, 168 registers do not hold its working set) stays saturated
+// (2^22: 12.2 vs 11.0 ms).  JFHIP_MSM_F29=0 / 1 forces saturated / 29-bit limbs (A/B measurements).
 static bool use_f29(int32_t curve, size_t n) {
     const char* e = getenv("JFHIP_MSM_F29");
     if (e && e[0] == '0') return false;
     if (e && e[0] == '1') return true;
-    return curve == JFHIP_BN254 && n <= ((size_t)1 << 22) + 4096;
+    (void)n;
+    return curve == JFHIP_BN254;
 }
 
 int32_t srs_build_table(jfhip_srs* srs, const uint32_t* d_points_packed, jfhip_stream* st) {
@@ -1088,10 +1135,14 @@ static int32_t msm_partial_t(const jfhip_srs* srs, size_t offset, const uint32_t
         set_error("msm too large: n * windows = %zu exceeds 2^32", total_max);
         return JFHIP_ERR_INVALID;
     }
-    // slice length: enough lanes to fill 256 CUs x 4 SIMDs x ~4 waves, at most 256 entries per lane
-    size_t L = (total_max + 262143) / 262144;
+    // slice length: one round of resident lanes (256 CUs x 4 SIMDs x 64 lanes x 4 waves of the saturated kernel, 3 of the
+    // 29-bit one: a second, partly filled round runs at a fraction of the chip), at most 256 entries per lane
+    static const int f29_occ = [] { const char* e = getenv("JFHIP_MSM_F29_OCC"); return e ? atoi(e) : 3; }();
+    const size_t lanes = (size_t)65536 * (srs->f29 ? (f29_occ >= 2 && f29_occ <= 4 ? f29_occ : 3) : 4);
+    // (more entries than lanes x 256: a whole number of such rounds)
+    const size_t rounds = (total_max + lanes * 256 - 1) / (lanes * 256);
+    size_t L = (total_max + lanes * rounds - 1) / (lanes * rounds);
     if (L < 16) L = 16;
-    if (L > 256) L = 256;
     const size_t T = (total_max + L - 1) / L;
     DigitPlan pl;
     pl.c = c;
@@ -1189,7 +1240,7 @@ static int32_t msm_partial_t(const jfhip_srs* srs, size_t offset, const uint32_t
     }
     pt.mark();
     if (srs->f29) {
-        static const int occ = [] { const char* e = getenv("JFHIP_MSM_F29_OCC"); return e ? atoi(e) : 3; }();
+        const int occ = f29_occ;
         auto kern = occ == 2 ? k_msm_accumulate29<Cv, 2> : occ == 3 ? k_msm_accumulate29<Cv, 3> : k_msm_accumulate29<Cv, 4>;
         constexpr size_t XR = 4 * F29<typename Cv::Fq>::L;
         const size_t elems = (size_t)B + 2 * T;

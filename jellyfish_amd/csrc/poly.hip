@@ -386,6 +386,11 @@ __global__ __launch_bounds__(128) void k_field_op(int op, const uint32_t* __rest
         r = f29_to_fp<C>(f29_sub<C, 4>(w, ab));
         break;
     }
+    case 11: {  // x y + (x^2 - y + 8p) y with one reduction
+        F29<C> a = f29_from_fp<C>(x), b = f29_from_fp<C>(y);
+        r = f29_to_fp<C>(f29_dot2<C>(a, b, f29_sub<C, 8>(f29_sqr<C>(a), b), b));
+        break;
+    }
     default: r = fp_to_mont<C>(x); break;
     }
     fp_store<C>(out + (size_t)i * C::N, r);

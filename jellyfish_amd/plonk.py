@@ -815,6 +815,24 @@ def unshard_quotient(cp, curve: int, gathered: torch.Tensor, m: int, out: torch.
                               stream=stream)
 
 
+def _row_ids(rows: torch.Tensor) -> torch.Tensor:
+    """equal rows (4 x int64) -> equal ids: one 64-bit radix sort of a mixing key instead of a lexicographic sort of the
+    256-bit rows (torch.unique(dim=0): 80 ms for 2^23 rows).  Exact: rows are compared in full between sorted neighbours,
+    and two different rows sharing a key (a 2^-64 event per pair) send the call to the lexicographic sort."""
+    key = rows[:, 0] * -7046029254386353131 + rows[:, 1] * -4417276706812531889 \
+        + rows[:, 2] * 1609587929392839161 + rows[:, 3] * -8796714831421723037
+    key = key ^ (key >> 29)
+    ks, order = torch.sort(key)
+    rs = rows[order]
+    diff_row = (rs[1:] != rs[:-1]).any(dim=1)
+    if bool(((ks[1:] == ks[:-1]) & diff_row).any().item()):
+        return torch.unique(rows, dim=0, return_inverse=True)[1]
+    ids_sorted = torch.cat([torch.zeros(1, dtype=torch.int64, device=rows.device), torch.cumsum(diff_row.to(torch.int64), 0)])
+    inv = torch.empty_like(ids_sorted)
+    inv[order] = ids_sorted
+    return inv
+
+
 def _sorted_lookup_vector(table: torch.Tensor, lookups: torch.Tensor) -> torch.Tensor:
     """compute_lookup_sorted_vec_polynomials (relation/src/constraint_system.rs:1597-1620) before its two iffts, on
     device rows of 4 x int64 (one field element each; equal elements have equal Montgomery limbs): every table element,
@@ -822,7 +840,7 @@ def _sorted_lookup_vector(table: torch.Tensor, lookups: torch.Tensor) -> torch.T
     the reference's HashMap entry is removed once used.  table: (n, 4), lookups: (n - 1, 4) -> (2n - 1, 4)."""
     n = table.shape[0]
     both = torch.cat([table, lookups])
-    _, inv = torch.unique(both, dim=0, return_inverse=True)
+    inv = _row_ids(both)
     tid, lid = inv[:n], inv[n:]
     nid = int(inv.max().item()) + 1
     counts = torch.bincount(lid, minlength=nid)

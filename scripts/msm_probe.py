@@ -10,7 +10,7 @@ L.set_profiling(True)
 for logn in [int(x) for x in sys.argv[1:]] or [24]:
     n = 1 << logn
     beta = bench.uniform_fr(1, 1, bench.BN254_R)[0]
-    srs = L.Srs.gen_for_testing(0, beta, bench.BN254_G, n)
+    srs = L.Srs.gen_for_testing(0, beta, bench.BN254_G, n, int(os.environ.get('JF_PROBE_C', '0')))
     sc_np = bench.uniform_fr(n, 2, bench.BN254_R)
     if os.environ.get("JF_PROBE_SCALARS") == "same":     # one bucket per window, table read in index order
         sc_np[:] = sc_np[0]

@@ -79,3 +79,5 @@ def test_unsaturated_29bit_arithmetic(hip, fname):
     assert (hip.field_op(fid, "sub29", A, B) == C.fp_binop(fid, "sub", A, B)).all()
     want = [(((x * y - 2 * x) * (x * x - y)) * y - x * y) % p for x, y in zip(xs, ys)]
     assert (hip.field_op(fid, "chain29", A, B) == mont_arr(f, want)).all()
+    want = [(x * y + (x * x - y) * y) % p for x, y in zip(xs, ys)]
+    assert (hip.field_op(fid, "dot29", A, B) == mont_arr(f, want)).all()
