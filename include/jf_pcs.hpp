@@ -23,6 +23,9 @@
 #include <cstring>
 #include <string>
 #include <utility>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <vector>
 
 #include "jfhip.h"
@@ -347,7 +350,80 @@ class UnivariateKzgPCS {
         return std::make_pair(std::move(proofs), std::move(evals));
     }
 
+    // ===== the trait's own signatures: commit / batch_commit / open take the HOST prover parameters =====
+    // (pcs/src/lib.rs:72-124: `fn commit(prover_param: impl Borrow<ProverParam>, poly)`.)  The reference uploads the SRS
+    // inside every gpu_commit (:664-680); a drop-in that did so would pay the upload + window table per commitment, so
+    // the device copy is cached process-wide per powers_of_g allocation, keyed on (data pointer, length): the
+    // PlonkKzgSnark prover passes the same ProvingKey::commit_key to all of its ~13-18 commits per proof.  The key is an
+    // address: call evict_prover_param(pp) before freeing or mutating a UnivariateProverParam whose commits went
+    // through these overloads (a Rust wrapper does it in Drop).  At most SRS_CACHE_MAX entries, least recently used out.
+    static constexpr size_t SRS_CACHE_MAX = 4;
+    static Result<std::shared_ptr<DeviceSrs<E>>> cached_prover_param(const UnivariateProverParam<E>& pp) {
+        if (pp.powers_of_g.empty()) return PCSError{PCSError::InvalidParameters, "empty prover parameters"};
+        auto& c = cache();
+        const Key key{pp.powers_of_g.data(), pp.powers_of_g.size()};
+        std::lock_guard<std::mutex> lk(c.mu);
+        auto it = c.map.find(key);
+        if (it != c.map.end()) {
+            it->second.second = ++c.clock;
+            return it->second.first;
+        }
+        auto srs = load_prover_param_to_gpu(pp, pp.powers_of_g.size() - 1);   // under the lock: one upload per key
+        if (srs.is_err()) return srs.unwrap_err();
+        if (c.map.size() >= SRS_CACHE_MAX) {
+            auto victim = c.map.begin();
+            for (auto j = c.map.begin(); j != c.map.end(); ++j)
+                if (j->second.second < victim->second.second) victim = j;
+            c.map.erase(victim);   // in-flight users keep their shared_ptr
+        }
+        auto sp = std::make_shared<DeviceSrs<E>>(std::move(srs.unwrap()));
+        c.map[key] = {sp, ++c.clock};
+        return sp;
+    }
+    static void evict_prover_param(const UnivariateProverParam<E>& pp) {
+        auto& c = cache();
+        std::lock_guard<std::mutex> lk(c.mu);
+        c.map.erase(Key{pp.powers_of_g.data(), pp.powers_of_g.size()});
+    }
+    static size_t cached_prover_params() {
+        auto& c = cache();
+        std::lock_guard<std::mutex> lk(c.mu);
+        return c.map.size();
+    }
+    static Result<Commitment<E>> commit(const UnivariateProverParam<E>& pp, const Polynomial& poly) {
+        if (poly.degree() > pp.powers_of_g.size())
+            return PCSError{PCSError::InvalidParameters, "poly degree " + std::to_string(poly.degree()) +
+                                                             " is larger than allowed " +
+                                                             std::to_string(pp.powers_of_g.size())};
+        auto srs = cached_prover_param(pp);
+        if (srs.is_err()) return srs.unwrap_err();
+        return commit(*srs.unwrap(), poly);
+    }
+    static Result<std::vector<Commitment<E>>> batch_commit(const UnivariateProverParam<E>& pp,
+                                                           const std::vector<Polynomial>& polys) {
+        if (polys.empty()) return std::vector<Commitment<E>>{};
+        auto srs = cached_prover_param(pp);
+        if (srs.is_err()) return srs.unwrap_err();
+        return batch_commit(*srs.unwrap(), polys);
+    }
+    static Result<std::pair<UnivariateKzgProof<E>, Evaluation>> open(const UnivariateProverParam<E>& pp,
+                                                                     const Polynomial& poly, const Point& point) {
+        auto srs = cached_prover_param(pp);
+        if (srs.is_err()) return srs.unwrap_err();
+        return open(*srs.unwrap(), poly, point);
+    }
+
    private:
+    using Key = std::pair<const void*, size_t>;
+    struct Cache {
+        std::mutex mu;
+        std::map<Key, std::pair<std::shared_ptr<DeviceSrs<E>>, uint64_t>> map;
+        uint64_t clock = 0;
+    };
+    static Cache& cache() {
+        static Cache* c = new Cache();   // never destroyed: no HIP calls from static destructors at exit
+        return *c;
+    }
     // icicle_projective_to_ark (:982-998): identity -> G1Affine::zero()
     static G1Affine<E> to_affine(const uint64_t* xy, uint8_t inf) {
         if (inf) return G1Affine<E>::zero();

@@ -97,6 +97,16 @@ int32_t jfhip_srs_load(int32_t curve_id, const void *points, size_t n, size_t st
 /* Same, from n packed affine points already in device memory. */
 int32_t jfhip_srs_load_device(int32_t curve_id, const void *d_points_packed, size_t n, int32_t window_bits,
                               jfhip_srs **out);
+/* Replaces the `powers_of_g` half of UnivariateUniversalParams::deserialize_{compressed,uncompressed}[_unchecked]
+ * (derive(CanonicalDeserialize) on the struct whose first field is `powers_of_g: Vec<E::G1Affine>`,
+ * pcs/src/univariate_kzg/srs.rs:17-31) + load_prover_param_to_gpu: `bytes` are n
+ * consecutive ark-serialize G1Affine records (the Vec's 8-byte length prefix already skipped): compressed (32 B BN254,
+ * 48 B BLS12-381) or uncompressed (64 / 96 B).  Decoding -- canonical -> Montgomery, y = sqrt(x^3 + b) with the sign
+ * the flag bits select, and with validate != 0 ark-serialize's Validate::Yes checks (on the curve; BLS12-381: in the
+ * prime-order subgroup) -- runs on the device, one lane per point.  A bad record is JFHIP_ERR_INVALID naming its index
+ * (ark's SerializationError::InvalidData).  window_bits as jfhip_srs_load. */
+int32_t jfhip_srs_load_serialized(int32_t curve_id, const uint8_t *bytes, size_t len, size_t n, int32_t compressed,
+                                  int32_t validate, int32_t window_bits, jfhip_srs **out);
 /* Replaces gen_srs_for_testing  (pcs/src/univariate_kzg/srs.rs:175-225) for harnesses:
  * builds [beta^i] g, i < n, on the device (beta: Fr Montgomery limbs, g: packed affine). */
 int32_t jfhip_srs_gen_for_testing(int32_t curve_id, const uint64_t *beta_mont, const uint64_t *g_xy, size_t n,
@@ -142,6 +152,14 @@ int32_t jfhip_msm_batch_device(const jfhip_srs *srs, const void *const *d_scalar
  * (load_commitments_to_host, :934-964). */
 int32_t jfhip_msm_device(const jfhip_srs *srs, size_t offset, const void *d_scalars_mont, size_t n, void *d_out,
                          jfhip_stream *stream);
+
+/* Variable-base MSM on HOST points: sum_i s_i * P_i for n packed affine points (Montgomery) that are NOT an SRS -- the
+ * verifier side: ScalarsAndBases::multi_scalar_mul -> VariableBaseMSM::msm_bigint (plonk/src/proof_system/structs.rs:
+ * 888-896) as Verifier::batch_verify_opening_proofs calls it (verifier.rs:231,251; ~30-60 commitments per proof) and
+ * the combinations of UnivariateKzgPCS::batch_verify (pcs/src/univariate_kzg/mod.rs:244-300).  Builds a throw-away window table for the points and runs the SRS path;
+ * out_xy / out_infinity as jfhip_msm.  n == 0 yields the identity. */
+int32_t jfhip_msm_small(int32_t curve_id, const uint64_t *points_xy, const uint64_t *scalars_mont, size_t n, void *out_xy,
+                        uint8_t *out_infinity, jfhip_stream *stream);
 
 /* Multi-GPU leg (no counterpart in the reference, which is single-device):
  * the un-normalised partial sum of this rank's point range as an XYZZ point
@@ -321,8 +339,8 @@ int32_t jfhip_witness_gather_device(const void *d_witness, size_t num_vars, cons
 
 /* field_id: 0 BN254 Fr, 1 BN254 Fq, 2 BLS12-381 Fr, 3 BLS12-381 Fq.
  * op: 0 add, 1 sub, 2 mul, 3 neg(a), 4 inv(a) (inv(0)=0), 5 from_mont(a), 6 to_mont(a);
- *     7 mul, 8 square(a), 9 sub, 10 ((ab - 2a)(a^2 - b))b - ab computed in the kernels' internal unsaturated
- *     29-bit-limb form (csrc/fp29.hpp) and converted back: same results as the saturated ops.
+ *     7 mul, 8 square(a), 9 sub, 10 ((ab - 2a)(a^2 - b))b - ab, 11 ab + (a^2 - b)b computed in the kernels' internal
+ *     unsaturated 29-bit-limb form (csrc/fp29.hpp) and converted back: same results as the saturated ops.
  * Host arrays of n elements; exercises the same device arithmetic the MSM/NTT kernels use. */
 int32_t jfhip_field_op(int32_t field_id, int32_t op, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n);
 

@@ -366,6 +366,57 @@ int32_t jfhip_srs_load_device(int32_t curve_id, const void* d_points_packed, siz
     return JFHIP_OK;
 }
 
+int32_t jfhip_srs_load_serialized(int32_t curve_id, const uint8_t* bytes, size_t len, size_t n, int32_t compressed,
+                                  int32_t validate, int32_t window_bits, jfhip_srs** out) {
+    if (!bytes || !out) {
+        set_error("null argument");
+        return JFHIP_ERR_INVALID;
+    }
+    JF_TRY(check_curve(curve_id));
+    const size_t fb = (size_t)fq_bytes(curve_id), rec = compressed ? fb : 2 * fb, pt = 2 * fb;
+    if (n == 0 || len / rec < n) {
+        set_error("%zu bytes hold %zu %s G1 records of %zu bytes, %zu requested", len, len / rec,
+                  compressed ? "compressed" : "uncompressed", rec, n);
+        return JFHIP_ERR_INVALID;
+    }
+    JF_STREAM(st, nullptr);
+    std::lock_guard<std::mutex> lk(st->mu);
+    jfhip_srs* srs = nullptr;
+    JF_TRY(srs_alloc(curve_id, n, window_bits, &srs));
+    DevBuf raw, packed, status;
+    uint32_t h_status[2] = {0u, 0xffffffffu};
+    int32_t rc = raw.ensure(n * rec);
+    if (rc == JFHIP_OK) rc = packed.ensure(n * pt);
+    if (rc == JFHIP_OK) rc = status.ensure(8);
+    if (rc == JFHIP_OK && (hipMemcpyAsync(raw.p, bytes, n * rec, hipMemcpyHostToDevice, st->s) != hipSuccess ||
+                           hipMemcpyAsync(status.p, h_status, 8, hipMemcpyHostToDevice, st->s) != hipSuccess))
+        rc = JFHIP_ERR_DEVICE;
+    if (rc == JFHIP_OK)
+        rc = srs_decode_points(curve_id, raw.as<uint8_t>(), n, compressed != 0, validate != 0, packed.as<uint32_t>(),
+                               status.as<uint32_t>(), st);
+    if (rc == JFHIP_OK && (hipMemcpyAsync(h_status, status.p, 8, hipMemcpyDeviceToHost, st->s) != hipSuccess ||
+                           hipStreamSynchronize(st->s) != hipSuccess))
+        rc = JFHIP_ERR_DEVICE;
+    if (rc == JFHIP_OK && h_status[0] != 0) {
+        // SerializationError::InvalidData of ark-serialize; the shim maps it to PCSError::InvalidParameters
+        set_error("G1 record %u is invalid:%s%s%s%s", h_status[1], (h_status[0] & 8) ? " malformed flags" : "",
+                  (h_status[0] & 1) ? " coordinate not below the modulus" : "",
+                  (h_status[0] & 2) ? " not on the curve" : "", (h_status[0] & 4) ? " not in the prime-order subgroup" : "");
+        rc = JFHIP_ERR_INVALID;
+    }
+    if (rc == JFHIP_OK) rc = srs_build_table(srs, packed.as<uint32_t>(), st);
+    if (rc == JFHIP_OK && hipStreamSynchronize(st->s) != hipSuccess) rc = JFHIP_ERR_DEVICE;
+    raw.release();
+    packed.release();
+    status.release();
+    if (rc != JFHIP_OK) {
+        jfhip_srs_free(srs);
+        return rc;
+    }
+    *out = srs;
+    return JFHIP_OK;
+}
+
 int32_t jfhip_srs_gen_for_testing(int32_t curve_id, const uint64_t* beta_mont, const uint64_t* g_xy, size_t n,
                                   int32_t window_bits, jfhip_srs** out) {
     if (!beta_mont || !g_xy || !out) {
@@ -563,6 +614,27 @@ int32_t jfhip_msm_batch_device(const jfhip_srs* srs, const void* const* d_scalar
                                 *out = d_scalars[b];
                                 return JFHIP_OK;
                             });
+}
+
+int32_t jfhip_msm_small(int32_t curve_id, const uint64_t* points_xy, const uint64_t* scalars, size_t n, void* out_xy,
+                        uint8_t* out_infinity, jfhip_stream* stream) {
+    if (!out_xy || !out_infinity || (n && (!points_xy || !scalars))) {
+        set_error("null argument");
+        return JFHIP_ERR_INVALID;
+    }
+    JF_TRY(check_curve(curve_id));
+    if (n == 0) {
+        memset(out_xy, 0, 2 * (size_t)fq_bytes(curve_id));
+        *out_infinity = 1;
+        return JFHIP_OK;
+    }
+    // bases change from call to call (the verifier's commitments), so the window table is built for this one product
+    // and dropped: the same kernels and the same exactness as the SRS path
+    jfhip_srs* tmp = nullptr;
+    JF_TRY(jfhip_srs_load(curve_id, points_xy, n, 2 * (size_t)fq_bytes(curve_id), 0, &tmp));
+    int32_t rc = jfhip_msm(tmp, 0, scalars, n, out_xy, out_infinity, stream);
+    jfhip_srs_free(tmp);
+    return rc;
 }
 
 int32_t jfhip_msm_batch(const jfhip_srs* srs, const uint64_t* const* scalars, const size_t* lens, size_t batch,

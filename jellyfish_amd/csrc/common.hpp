@@ -186,6 +186,8 @@ int32_t srs_build_table(jfhip_srs* srs, const uint32_t* d_points_packed, jfhip_s
 int32_t table_rescale(int32_t curve, uint32_t* d_pts, size_t count, int up, hipStream_t s);
 int32_t srs_gen_points(int32_t curve, const uint64_t* beta_mont, const uint64_t* g_xy, size_t n, uint32_t* d_out,
                        jfhip_stream* st);
+int32_t srs_decode_points(int32_t curve, const uint8_t* d_raw, size_t n, int compressed, int validate, uint32_t* d_out,
+                          uint32_t* d_status, jfhip_stream* st);
 int32_t srs_pack_points(int32_t curve, const uint8_t* d_raw, size_t n, size_t stride, uint32_t* d_out,
                         jfhip_stream* st);
 int32_t ntt_device(int32_t curve, uint32_t* d_data, uint32_t log_n, size_t batch, int inverse,

@@ -353,6 +353,15 @@ JF_HD Fp<C> fp_mul(const Fp<C>& a, const Fp<C>& b) {
 }
 #endif
 
+// equality of two fully reduced values
+template <class C>
+JF_HD bool fp_eq(const Fp<C>& a, const Fp<C>& b) {
+    uint32_t d = 0;
+#pragma unroll
+    for (int i = 0; i < C::N; i++) d |= a.v[i] ^ b.v[i];
+    return d == 0;
+}
+
 template <class C>
 JF_HD Fp<C> fp_sqr(const Fp<C>& a) {
     return fp_mul<C>(a, a);

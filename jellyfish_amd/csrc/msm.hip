@@ -942,6 +942,165 @@ __global__ __launch_bounds__(128) void k_srs_gen(const uint32_t* __restrict__ be
 }
 
 // ---- small group ops for the test surface ---------------------------------------------------
+// ---- ark-serialize G1Affine records -> packed affine Montgomery points -------------------------------------
+// limb i of (p + 1) / 4 (both base fields are 3 mod 4: a square root of a residue a is a^((p+1)/4))
+template <class C>
+JF_HD constexpr uint32_t sqrt_exp_limb(int i) {
+    // (p + 1) >> 2 on the limbs, with the carry of the +1
+    uint32_t carry = 1, lo = 0, hi = 0;
+    for (int k = 0; k <= i + 1 && k < C::N; k++) {
+        uint64_t t = (uint64_t)C::P(k) + carry;
+        carry = (uint32_t)(t >> 32);
+        if (k == i) lo = (uint32_t)t;
+        if (k == i + 1) hi = (uint32_t)t;
+    }
+    if (i + 1 >= C::N) hi = carry;   // p + 1 never carries out of N limbs for these moduli, kept for exactness
+    return (lo >> 2) | (hi << 30);
+}
+template <class C>
+__device__ __noinline__ Fp<C> fp_sqrt_candidate(const Fp<C>& a) {
+    constexpr int N = C::N;
+    Fp<C> acc = Fp<C>::one();
+    for (int i = N - 1; i >= 0; i--) {
+        uint32_t e = 0;
+#pragma unroll
+        for (int j = 0; j < N; j++) e = (j == i) ? sqrt_exp_limb<C>(j) : e;
+        for (int b = 31; b >= 0; b--) {
+            acc = fp_sqr<C>(acc);
+            if ((e >> b) & 1u) acc = fp_mul<C>(acc, a);
+        }
+    }
+    return acc;
+}
+// a > b on canonical (non-Montgomery) limbs
+template <class C>
+JF_DEV bool fp_canon_gt(const Fp<C>& a, const Fp<C>& b) {
+    for (int i = C::N - 1; i >= 0; i--) {
+        if (a.v[i] != b.v[i]) return a.v[i] > b.v[i];
+    }
+    return false;
+}
+template <class C>
+JF_DEV bool fp_canon_lt_p(const Fp<C>& a) {
+    for (int i = C::N - 1; i >= 0; i--) {
+        if (a.v[i] != C::P(i)) return a.v[i] < C::P(i);
+    }
+    return false;
+}
+// limb i of the scalar-field modulus r, as an exponent for the subgroup check
+template <class Cv>
+JF_DEV XYZZ<Cv> xyzz_mul_by_r(const Affine<Cv>& p) {
+    using Fr = typename Cv::Fr;
+    XYZZ<Cv> r = XYZZ<Cv>::identity();
+    for (int i = Fr::N - 1; i >= 0; i--) {
+        uint32_t e = 0;
+#pragma unroll
+        for (int j = 0; j < Fr::N; j++) e = (j == i) ? Fr::P(j) : e;
+        for (int b = 31; b >= 0; b--) {
+            r = xyzz_double<Cv>(r);
+            if ((e >> b) & 1u) xyzz_add_affine<Cv>(r, p);
+        }
+    }
+    return r;
+}
+
+// status[0]: OR of failure bits (1 not canonical, 2 not on the curve / no square root, 4 not in the r-torsion subgroup,
+// 8 malformed flags), status[1]: smallest failing index (atomicMin).
+// Formats (ark-serialize 0.4/0.5):
+//   BN254 (ark-ec short Weierstrass default): x little-endian, flags in the top bits of the LAST byte (0x80: y is the
+//     larger of {y, -y}; 0x40: infinity); uncompressed appends y little-endian, which carries the flags instead.
+//   BLS12-381 (ark-bls12-381's own impl = the zcash encoding): x big-endian, flags in the top bits of the FIRST byte
+//     (0x80 compressed, 0x40 infinity, 0x20 y is the larger); uncompressed appends y big-endian.
+template <class Cv>
+__global__ __launch_bounds__(128) void k_srs_decode(const uint8_t* __restrict__ raw, uint32_t n, int compressed,
+                                                    int validate, uint32_t* __restrict__ out,
+                                                    uint32_t* __restrict__ status) {
+    using Q = typename Cv::Fq;
+    constexpr int N = Q::N, FB = 4 * N, PT = 2 * N;
+    constexpr bool BE = Cv::ID == 1;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const size_t rec = compressed ? FB : 2 * FB;
+    const uint8_t* src = raw + (size_t)i * rec;
+    auto fail = [&](uint32_t bit) {
+        atomicOr(&status[0], bit);
+        atomicMin(&status[1], i);
+        for (int k = 0; k < PT; k++) out[(size_t)i * PT + k] = 0;
+    };
+    auto read = [&](const uint8_t* b, Fp<Q>& f) {
+        for (int w = 0; w < N; w++) {
+            uint32_t v = 0;
+            for (int k = 0; k < 4; k++) {
+                const int byte = 4 * w + k;   // little-endian byte index
+                v |= (uint32_t)b[BE ? FB - 1 - byte : byte] << (8 * k);
+            }
+            f.v[w] = v;
+        }
+    };
+    // flags live in the most significant byte of x (compressed) or of the flag-carrying coordinate
+    const uint8_t* fsrc = BE ? src : (compressed ? src : src + FB);
+    const uint8_t fbyte = BE ? fsrc[0] : fsrc[FB - 1];
+    bool infinity, y_larger;
+    if (BE) {
+        const bool cflag = (fbyte & 0x80) != 0;
+        infinity = (fbyte & 0x40) != 0;
+        y_larger = (fbyte & 0x20) != 0;
+        if (cflag != (compressed != 0) || (!compressed && y_larger)) return fail(8);
+    } else {
+        infinity = (fbyte & 0x40) != 0;
+        y_larger = (fbyte & 0x80) != 0;
+        if (infinity && y_larger) return fail(8);
+    }
+    Fp<Q> x, y;
+    read(src, x);
+    if (!compressed) read(src + FB, y);
+    // clear the flag bits from the coordinate that carried them
+    const uint32_t clear = BE ? 0x1fffffffu : 0x3fffffffu;
+    if (BE || compressed) x.v[N - 1] &= clear;
+    else y.v[N - 1] &= clear;
+    if (infinity) {
+        bool zero = x.is_zero() && (compressed || y.is_zero());
+        if (!zero) return fail(8);
+        for (int k = 0; k < PT; k++) out[(size_t)i * PT + k] = 0;
+        return;
+    }
+    if (!fp_canon_lt_p<Q>(x) || (!compressed && !fp_canon_lt_p<Q>(y))) return fail(1);
+    Affine<Cv> p;
+    p.x = fp_to_mont<Q>(x);
+    // the curve coefficient b (3 for BN254, 4 for BLS12-381) in Montgomery form, by additions of one()
+    const Fp<Q> two = fp_dbl<Q>(Fp<Q>::one());
+    const Fp<Q> bcoef = Cv::ID == 0 ? fp_add<Q>(two, Fp<Q>::one()) : fp_dbl<Q>(two);
+    const Fp<Q> rhs = fp_add<Q>(fp_mul<Q>(fp_sqr<Q>(p.x), p.x), bcoef);
+    if (compressed) {
+        Fp<Q> cand = fp_sqrt_candidate<Q>(rhs);
+        if (!fp_eq<Q>(fp_sqr<Q>(cand), rhs)) return fail(2);
+        const Fp<Q> neg = fp_neg<Q>(cand);
+        const bool cand_larger = fp_canon_gt<Q>(fp_from_mont<Q>(cand), fp_from_mont<Q>(neg));
+        p.y = (cand_larger == y_larger) ? cand : neg;
+    } else {
+        p.y = fp_to_mont<Q>(y);
+        if (validate && !fp_eq<Q>(fp_sqr<Q>(p.y), rhs)) return fail(2);
+    }
+    if (validate && Cv::ID == 1) {   // BN254 G1 has cofactor 1
+        XYZZ<Cv> t = xyzz_mul_by_r<Cv>(p);
+        if (!t.is_inf()) return fail(4);
+    }
+    affine_store<Cv>(out + (size_t)i * PT, p);
+}
+
+int32_t srs_decode_points(int32_t curve, const uint8_t* d_raw, size_t n, int compressed, int validate, uint32_t* d_out,
+                          uint32_t* d_status, jfhip_stream* st) {
+    dim3 grid((unsigned)((n + 127) / 128));
+    if (curve == JFHIP_BN254)
+        hipLaunchKernelGGL((k_srs_decode<Bn254G1>), grid, dim3(128), 0, st->s, d_raw, (uint32_t)n, compressed, validate,
+                           d_out, d_status);
+    else
+        hipLaunchKernelGGL((k_srs_decode<Bls381G1>), grid, dim3(128), 0, st->s, d_raw, (uint32_t)n, compressed, validate,
+                           d_out, d_status);
+    JF_HIP(hipGetLastError());
+    return JFHIP_OK;
+}
+
 template <class Cv>
 __global__ void k_g1_op(int op, const uint32_t* __restrict__ P, const uint32_t* __restrict__ Qp,
                         uint32_t* __restrict__ out) {
@@ -1020,14 +1179,15 @@ static int32_t srs_build_table_t(jfhip_srs* srs, jfhip_stream* st) {
 // Which arithmetic the bucket accumulation of an SRS uses.  Measured on MI355X (uniform scalars), bucket_accumulate phase,
 // 29-bit limbs vs saturated: BN254 2^20 points 1.24 vs 1.59 ms, 2^22 4.24 vs 5.29, 2^24 14.9 vs 18.3 -- the 29-bit kernel
 // everywhere (profiles/r02_*; before the gather of its software pipeline was moved behind the bucket hand-over it LOST at
-// 2^24, 20.7 ms).  BLS12-381 (14 limbs of 29 bits, 168 registers do not hold its working set) stays saturated
-// (2^22: 12.2 vs 11.0 ms).  JFHIP_MSM_F29=0 / 1 forces saturated / 29-bit limbs (A/B measurements).
+// 2^24, 20.7 ms, and BLS12-381 at every size).  BLS12-381 (14 limbs of 29 bits): 2^20 2.97 vs 3.56 ms, 2^22 8.99 vs 11.28.
+// JFHIP_MSM_F29=0 / 1 forces saturated / 29-bit limbs (A/B measurements).
 static bool use_f29(int32_t curve, size_t n) {
     const char* e = getenv("JFHIP_MSM_F29");
     if (e && e[0] == '0') return false;
     if (e && e[0] == '1') return true;
+    (void)curve;
     (void)n;
-    return curve == JFHIP_BN254;
+    return true;
 }
 
 int32_t srs_build_table(jfhip_srs* srs, const uint32_t* d_points_packed, jfhip_stream* st) {

@@ -33,6 +33,7 @@ def library_path() -> str:
 SYMBOLS = [
     "jfhip_init", "jfhip_shutdown", "jfhip_cache_clear", "jfhip_stream_release_workspace", "jfhip_last_error", "jfhip_device_count", "jfhip_stream_create", "jfhip_stream_destroy",
     "jfhip_stream_sync", "jfhip_stream_raw", "jfhip_stream_wrap", "jfhip_srs_load", "jfhip_srs_load_device",
+    "jfhip_srs_load_serialized", "jfhip_msm_small",
     "jfhip_srs_gen_for_testing", "jfhip_srs_free", "jfhip_srs_len", "jfhip_srs_window_bits", "jfhip_srs_read",
     "jfhip_msm", "jfhip_msm_batch", "jfhip_msm_batch_device", "jfhip_msm_device", "jfhip_msm_partial_device", "jfhip_g1_sum_partials",
     "jfhip_kzg_open", "jfhip_ntt", "jfhip_ntt_device", "jfhip_plonk_quotient_turbo_device", "jfhip_plonk_quotient_ultra_device", "jfhip_plonk_quotient_coset_device", "jfhip_plonk_quotient_masked_device", "jfhip_plonk_perm_product_device", "jfhip_plonk_lookup_product_device", "jfhip_plonk_lookup_merge_device", "jfhip_witness_gather_device", "jfhip_poly_divide_linear_device", "jfhip_poly_divide_linear_noalloc_device",
@@ -163,6 +164,16 @@ class Srs:
         return cls(h, curve)
 
     @classmethod
+    def load_serialized(cls, curve: int, data: bytes, n: int, compressed: bool = True, validate: bool = True,
+                        window_bits: int = 0) -> "Srs":
+        """n ark-serialize G1Affine records (the Vec length prefix already skipped), decoded on the device"""
+        buf = np.frombuffer(data, dtype=np.uint8)
+        h = ctypes.c_void_p()
+        _check(load_library().jfhip_srs_load_serialized(curve, _p(buf), ctypes.c_size_t(buf.size), ctypes.c_size_t(n),
+                                                        int(compressed), int(validate), window_bits, ctypes.byref(h)))
+        return cls(h, curve)
+
+    @classmethod
     def load_device(cls, curve: int, d_points: int, n: int, window_bits: int = 0) -> "Srs":
         h = ctypes.c_void_p()
         _check(load_library().jfhip_srs_load_device(curve, _vp(d_points), ctypes.c_size_t(n), window_bits,
@@ -209,6 +220,17 @@ def msm(srs: Srs, scalars_mont, offset: int = 0, stream: Stream | None = None):
     inf = ctypes.c_uint8(0)
     _check(load_library().jfhip_msm(srs.h, ctypes.c_size_t(offset), _p(sc) if n else None, ctypes.c_size_t(n), _p(out),
                                     ctypes.byref(inf), _sh(stream)))
+    return out, bool(inf.value)
+
+
+def msm_small(curve: int, points_xy, scalars_mont, stream: Stream | None = None):
+    """variable-base MSM on host points (verifier side) -> (packed affine point, is_identity)"""
+    pts, sc = _u64(points_xy), _u64(scalars_mont)
+    n = sc.size // 4
+    out = np.zeros(2 * FQ_LIMBS64[curve], dtype=np.uint64)
+    inf = ctypes.c_uint8(0)
+    _check(load_library().jfhip_msm_small(curve, _p(pts) if n else None, _p(sc) if n else None, ctypes.c_size_t(n),
+                                          _p(out), ctypes.byref(inf), _sh(stream)))
     return out, bool(inf.value)
 
 

@@ -9,13 +9,15 @@ L.init(0)
 L.set_profiling(True)
 for logn in [int(x) for x in sys.argv[1:]] or [24]:
     n = 1 << logn
-    beta = bench.uniform_fr(1, 1, bench.BN254_R)[0]
-    srs = L.Srs.gen_for_testing(0, beta, bench.BN254_G, n, int(os.environ.get('JF_PROBE_C', '0')))
-    sc_np = bench.uniform_fr(n, 2, bench.BN254_R)
+    bls = os.environ.get("JF_PROBE_CURVE") == "bls"
+    R_, G_, cid = (bench.BLS_R, bench.BLS_G, 1) if bls else (bench.BN254_R, bench.BN254_G, 0)
+    beta = bench.uniform_fr(1, 1, R_)[0]
+    srs = L.Srs.gen_for_testing(cid, beta, G_, n, int(os.environ.get('JF_PROBE_C', '0')))
+    sc_np = bench.uniform_fr(n, 2, R_)
     if os.environ.get("JF_PROBE_SCALARS") == "same":     # one bucket per window, table read in index order
         sc_np[:] = sc_np[0]
     sc = torch.from_numpy(sc_np.view(np.int64)).cuda()
-    out = torch.zeros(128, dtype=torch.uint8, device="cuda")
+    out = torch.zeros(256, dtype=torch.uint8, device="cuda")
     st = L.Stream()
     for _ in range(3):
         torch.cuda.synchronize(); t = time.time()

@@ -108,6 +108,37 @@ static void run(const uint64_t* g_xy) {
         CHECK(comms2.is_ok());
         for (size_t i = 0; i < bs; i++) CHECK(comms2.unwrap()[i] == comms.unwrap()[i]);
     }
+    // the trait's signatures (host prover parameters): one cached upload per powers_of_g allocation
+    {
+        PCS::evict_prover_param(pp);
+        const size_t before = PCS::cached_prover_params();
+        DensePolynomial p = rand_poly(700);
+        auto c1 = PCS::commit(pp, p);
+        CHECK(c1.is_ok() && c1.unwrap() == cpu_commit(p));
+        CHECK(PCS::cached_prover_params() == before + 1);
+        auto c2 = PCS::commit(pp, p);
+        CHECK(c2.is_ok() && c2.unwrap() == c1.unwrap());
+        CHECK(PCS::cached_prover_params() == before + 1);
+        std::vector<DensePolynomial> polys{rand_poly(5), rand_poly(900), p};
+        auto bc = PCS::batch_commit(pp, polys);
+        CHECK(bc.is_ok() && bc.unwrap().size() == 3 && bc.unwrap()[2] == c1.unwrap());
+        Fr z = rand_fr();
+        auto o1 = PCS::open(pp, p, z);
+        auto o2 = PCS::open(srs.unwrap(), p, z);
+        CHECK(o1.is_ok() && o2.is_ok() && o1.unwrap().second == o2.unwrap().second);
+        CHECK(o1.unwrap().first.proof == o2.unwrap().first.proof);
+        auto e = PCS::commit(pp, rand_poly(supported_degree + 5));
+        CHECK(e.is_err() && e.unwrap_err().msg.find("larger than allowed") != std::string::npos);
+        // a prefix view of the same allocation is a different key (different length)
+        UnivariateProverParam<E> half;
+        half.powers_of_g.assign(pp.powers_of_g.begin(), pp.powers_of_g.begin() + 2049);
+        auto c3 = PCS::commit(half, p);
+        CHECK(c3.is_ok() && c3.unwrap() == c1.unwrap());
+        CHECK(PCS::cached_prover_params() == before + 2);
+        PCS::evict_prover_param(half);
+        PCS::evict_prover_param(pp);
+        CHECK(PCS::cached_prover_params() == before);
+    }
     // empty batch -> Ok(vec![])
     CHECK(PCS::gpu_batch_commit(pp, {}).is_ok());
     CHECK(PCS::gpu_batch_commit(pp, {}).unwrap().empty());

@@ -26,6 +26,36 @@ def test_library_exports_every_declared_symbol():
     assert sorted(L.SYMBOLS) == syms
 
 
+def _c_arg_counts():
+    text = open(os.path.join(ROOT, "include", "jfhip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    out = {}
+    for name, args in re.findall(r"\b(jfhip_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", text):
+        args = args.strip()
+        out[name] = 0 if args in ("", "void") else args.count(",") + 1
+    return out
+
+
+def test_rust_sys_crate_declares_every_symbol_with_the_same_arity():
+    """rust/jf-hip-sys cannot be compiled here (no Rust toolchain): keep it in step with the header textually --
+    every function the header declares is an `pub fn` of the extern block with the same number of arguments, and the
+    crate declares nothing the header does not."""
+    src = open(os.path.join(ROOT, "rust", "jf-hip-sys", "src", "lib.rs")).read()
+    src = re.sub(r"//.*", "", src)
+    rust = {}
+    for name, args in re.findall(r"pub fn (jfhip_[a-z0-9_]+)\s*\(([^)]*)\)", src, flags=re.S):
+        args = args.strip().rstrip(",")
+        rust[name] = 0 if not args else args.count(",") + 1
+    c = _c_arg_counts()
+    assert sorted(rust) == sorted(c)
+    assert rust == c
+    for f in ("Cargo.toml", "build.rs"):
+        assert os.path.exists(os.path.join(ROOT, "rust", "jf-hip-sys", f))
+    patch = open(os.path.join(ROOT, "rust", "patches", "jf-pcs-hip.patch")).read()
+    for sym in ("jfhip_srs_load", "jfhip_msm", "jfhip_msm_batch", "jfhip_kzg_open", "jfhip_last_error", "jfhip_srs_free"):
+        assert sym in patch and sym in c
+
+
 def test_no_device_is_reported_not_crashed():
     if L.device_count() > 0:
         pytest.skip("a GPU is visible")

@@ -235,3 +235,115 @@ def test_msm_sparse_scalars_skip_empty_buckets(hip, f29, monkeypatch):
     t_dense, t_sparse = timed(dense), timed(sparse)
     assert t_sparse < 1.5 * t_dense, (t_sparse, t_dense)
     srs.free()
+
+
+def _ser_uncompressed(cv, P) -> bytes:
+    """ark-serialize uncompressed G1Affine (formats: include/jfhip.h, jfhip_srs_load_serialized)"""
+    p = cv.fq.p
+    nb = 8 * cv.fq.limbs64
+    if cv.name == "bn254":
+        if P is None:
+            b = bytearray(2 * nb)
+            b[-1] |= 0x40
+            return bytes(b)
+        b = bytearray(P[0].to_bytes(nb, "little") + P[1].to_bytes(nb, "little"))
+        if P[1] > (p - P[1]) % p:
+            b[-1] |= 0x80
+        return bytes(b)
+    if P is None:
+        b = bytearray(2 * nb)
+        b[0] |= 0x40
+        return bytes(b)
+    return P[0].to_bytes(nb, "big") + P[1].to_bytes(nb, "big")
+
+
+def test_srs_load_serialized_decodes_on_the_device(hip, setup):
+    """jfhip_srs_load_serialized: compressed and uncompressed ark-serialize records -> the same device SRS as loading the
+    in-memory points; invalid records are refused with their index.  The byte formats are the restated ones of
+    oracle/plonk_ref.py (no serialized G1 fixture exists in the reference: parity with arkworks' bytes is unpinned)."""
+    from oracle import plonk_ref as PR
+
+    cv, _, srs_host, _ = setup
+    n = 700
+    pts = [pt_from(cv, srs_host[i]) for i in range(n)]
+    pts[5] = None
+    pts[n - 1] = None
+    want = srs_host[:n].copy()
+    want[5] = 0
+    want[n - 1] = 0
+    for compressed, ser in ((True, lambda P: PR.ser_g1(cv, P)), (False, lambda P: _ser_uncompressed(cv, P))):
+        blob = b"".join(ser(P) for P in pts)
+        for validate in (True, False):
+            s = hip.Srs.load_serialized(cv.curve_id, blob + b"\x00" * 7, n, compressed=compressed, validate=validate)
+            assert len(s) == n
+            assert (s.read(0, n) == want).all(), (compressed, validate)
+            sc = rand_fr_mont(cv, n, 99)
+            got, inf = hip.msm(s, sc)
+            assert not inf and (got == C.msm(cv.curve_id, want, sc)).all()
+            s.free()
+        # too few bytes
+        with pytest.raises(hip.JfHipError, match="records"):
+            hip.Srs.load_serialized(cv.curve_id, blob[:-1], n, compressed=compressed)
+    p, nb = cv.fq.p, 8 * cv.fq.limbs64
+    b_coef = 3 if cv.name == "bn254" else 4
+    order = "little" if cv.name == "bn254" else "big"
+
+    def with_x(x, flag_compressed=True):
+        b = bytearray(x.to_bytes(nb, order))
+        if cv.name != "bn254":
+            b[0] |= 0x80
+        return bytes(b)
+
+    good = PR.ser_g1(cv, pts[0])
+    # x >= p
+    with pytest.raises(hip.JfHipError, match="record 1 .*modulus"):
+        hip.Srs.load_serialized(cv.curve_id, good + with_x(p) + good, 3)
+    # x^3 + b is not a square
+    x = 2
+    while pow((x ** 3 + b_coef) % p, (p - 1) // 2, p) == 1:
+        x += 1
+    with pytest.raises(hip.JfHipError, match="record 2 .*curve"):
+        hip.Srs.load_serialized(cv.curve_id, good + good + with_x(x), 3)
+    # uncompressed point off the curve: caught only when validating
+    bad = _ser_uncompressed(cv, (pts[0][0], (pts[0][1] + 1) % p))
+    with pytest.raises(hip.JfHipError, match="record 0 .*curve"):
+        hip.Srs.load_serialized(cv.curve_id, bad, 1, compressed=False, validate=True)
+    hip.Srs.load_serialized(cv.curve_id, bad, 1, compressed=False, validate=False).free()
+    if cv.name != "bn254":
+        # on the curve but outside the prime-order subgroup (cofactor != 1): Validate::Yes refuses it
+        x = 1
+        while True:
+            rhs = (x ** 3 + b_coef) % p
+            if pow(rhs, (p - 1) // 2, p) == 1:
+                y = pow(rhs, (p + 1) // 4, p)
+                if R.ec_add(cv, R.ec_mul(cv, cv.fr.p - 1, (x, y)), (x, y)) is not None:
+                    break
+            x += 1
+        with pytest.raises(hip.JfHipError, match="subgroup"):
+            hip.Srs.load_serialized(cv.curve_id, with_x(x), 1, validate=True)
+        s = hip.Srs.load_serialized(cv.curve_id, with_x(x), 1, validate=False)
+        got = pt_from(cv, s.read(0, 1)[0])
+        assert got[0] == x and got[1] in (y, p - y) and got[1] <= (p - got[1]) % p   # flag clear: the smaller root
+        s.free()
+        # compression flag missing
+        with pytest.raises(hip.JfHipError, match="flags"):
+            hip.Srs.load_serialized(cv.curve_id, pts[0][0].to_bytes(nb, "big"), 1)
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 37, 300])
+def test_msm_small_on_host_points(hip, setup, n):
+    """jfhip_msm_small (verifier-side VariableBaseMSM over commitments): arbitrary bases, no SRS"""
+    cv, _, srs_host, _ = setup
+    rng = np.random.default_rng(n)
+    idx = rng.integers(0, len(srs_host), size=n)
+    pts = srs_host[idx].copy()
+    if n > 5:
+        pts[3] = 0          # an identity among the bases
+        pts[4] = pts[2]     # a repeated base
+    sc = rand_fr_mont(cv, n, 500 + n)
+    got, inf = hip.msm_small(cv.curve_id, pts, sc)
+    if n == 0:
+        assert inf
+        return
+    exp = C.msm(cv.curve_id, pts, sc)
+    assert (got == exp).all() and inf == (not exp.any())
