@@ -437,6 +437,44 @@ JF_DEV void xyzz29_store_raw(uint32_t* __restrict__ dst, const XYZZ29<Cv>& a, bo
         reinterpret_cast<uint4*>(dst)[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
 }
 
+template <class Cv>
+JF_DEV bool xyzz29_load_raw(const uint32_t* __restrict__ src, XYZZ29<Cv>& a) {   // returns "is the identity"
+    constexpr int L = F29<typename Cv::Fq>::L;
+    uint32_t w[4 * L];
+#pragma unroll
+    for (int k = 0; k < L; k++) {
+        const uint4 q = reinterpret_cast<const uint4*>(src)[k];
+        w[4 * k] = q.x;
+        w[4 * k + 1] = q.y;
+        w[4 * k + 2] = q.z;
+        w[4 * k + 3] = q.w;
+    }
+    uint32_t nz = 0;
+#pragma unroll
+    for (int k = 0; k < L; k++) {
+        a.X.v[k] = w[k];
+        a.Y.v[k] = w[L + k];
+        a.ZZ.v[k] = w[2 * L + k];
+        a.ZZZ.v[k] = w[3 * L + k];
+        nz |= w[2 * L + k];
+    }
+    return nz == 0;
+}
+// element idx of an array the accumulation wrote: saturated XYZZ (RAW = false) or the 29-bit kernel's raw form
+// (RAW = true: 4 L29 words, lazily reduced, all zero = identity), converted on load.  The stages after the accumulation
+// read only what they need -- one element per slice boundary, one per bucket -- instead of a conversion pass over all
+// B + 2 T elements (at 2^20 points: 65536 buckets but 393216 partial slots, 0.17 ms).
+template <class Cv, bool RAW>
+JF_DEV XYZZ<Cv> elem_load(const uint32_t* __restrict__ base, size_t idx) {
+    if constexpr (!RAW) {
+        return xyzz_load<Cv>(base + idx * (4 * Cv::Fq::N));
+    } else {
+        XYZZ29<Cv> a;
+        const bool inf = xyzz29_load_raw<Cv>(base + idx * (4 * F29<typename Cv::Fq>::L), a);
+        return xyzz29_to_std<Cv>(a, inf);
+    }
+}
+
 // rare path of the mixed add (P + P or P - P): fall back to the saturated formulas, out of line.  Everything goes
 // in and out BY VALUE: a reference would make the hot loop's accumulator escape into scratch memory.
 template <class Cv>
@@ -472,8 +510,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
                                                           uint32_t* __restrict__ partB) {
     // buckets / partA / partB are RAW here: 4 L29 words per element, lazily reduced 29-bit limbs, all zero = identity.
     // Converting to the saturated form inside flush() would put ~1400 instructions on a branch that some lane of
-    // a wave takes in half of all iterations (average bucket ~ 96 entries, 64 lanes); k_xyzz29_to_std converts
-    // afterwards, one element per lane, fully convergent.
+    // a wave takes in half of all iterations (average bucket ~ 96 entries, 64 lanes); the fix-up and the fold convert
+    // the elements they read (elem_load<RAW>).
     using Q = typename Cv::Fq;
     using F = F29<Q>;
     constexpr int PT = 2 * Q::N;
@@ -625,33 +663,6 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     if (!wroteB) xyzz29_store_raw<Cv>(partB + (size_t)t * XZ, acc, true);
 }
 
-// raw (4 L29 words, lazily reduced) -> saturated XYZZ, one element per lane: elements [0, B) are buckets,
-// [B, B + T) the slices' leading partial runs, [B + T, B + 2T) the trailing ones
-template <class Cv>
-__global__ __launch_bounds__(256) void k_xyzz29_to_std(const uint32_t* __restrict__ raw, uint32_t B, uint32_t T,
-                                                       uint32_t* __restrict__ buckets, uint32_t* __restrict__ partA,
-                                                       uint32_t* __restrict__ partB) {
-    using Q = typename Cv::Fq;
-    using F = F29<Q>;
-    constexpr int XZ = 4 * Q::N;
-    constexpr int XR = 4 * F::L;
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (size_t)B + 2 * (size_t)T) return;
-    const uint32_t* src = raw + i * XR;
-    XYZZ29<Cv> a;
-    uint32_t nz = 0;
-#pragma unroll
-    for (int k = 0; k < F::L; k++) {
-        a.X.v[k] = src[k];
-        a.Y.v[k] = src[F::L + k];
-        a.ZZ.v[k] = src[2 * F::L + k];
-        a.ZZZ.v[k] = src[3 * F::L + k];
-        nz |= a.ZZ.v[k];
-    }
-    uint32_t* dst = i < B ? buckets + i * XZ : (i < (size_t)B + T ? partA + (i - B) * XZ : partB + (i - B - T) * XZ);
-    xyzz_store<Cv>(dst, xyzz29_to_std<Cv>(a, nz == 0));
-}
-
 // table entries x -> x 2^(+-SHIFT): saturated Montgomery factor R <-> R' (identity entries (0, 0) are unchanged)
 template <class Cv>
 __global__ __launch_bounds__(256) void k_table_rescale(uint32_t* __restrict__ pts, size_t count, int up) {
@@ -676,7 +687,9 @@ int32_t table_rescale(int32_t curve, uint32_t* d_pts, size_t count, int up, hipS
 // (skewed scalars: all-equal scalars put n entries into one bucket per window = 65536 slices at 2^24, 0.8 s of serial
 // additions on one lane) is queued for k_msm_fixup_heavy instead.
 constexpr uint32_t HEAVY_SPAN = 48;
-template <class Cv>
+// partA / partB: what the accumulation wrote (RAW: the 29-bit kernel's form); buckets: saturated, written here for the
+// spanning buckets only -- k_msm_bucket_fold takes every other bucket from the accumulation's own array.
+template <class Cv, bool RAW>
 __global__ __launch_bounds__(128) void k_msm_fixup(const uint32_t* __restrict__ off, uint32_t B, uint32_t L,
                                                    const uint32_t* __restrict__ partA,
                                                    const uint32_t* __restrict__ partB,
@@ -692,16 +705,16 @@ __global__ __launch_bounds__(128) void k_msm_fixup(const uint32_t* __restrict__ 
         heavy[1 + atomicAdd(heavy, 1u)] = b;
         return;
     }
-    XYZZ<Cv> acc = xyzz_load<Cv>(((s % L == 0) ? partA : partB) + (size_t)t1 * XZ);
+    XYZZ<Cv> acc = elem_load<Cv, RAW>((s % L == 0) ? partA : partB, t1);
     for (uint32_t t = t1 + 1; t <= t2; t++) {
-        XYZZ<Cv> q = xyzz_load<Cv>(partA + (size_t)t * XZ);
+        XYZZ<Cv> q = elem_load<Cv, RAW>(partA, t);
         xyzz_add_inl<Cv>(acc, q);
     }
     xyzz_store<Cv>(buckets + (size_t)b * XZ, acc);
 }
 
 // one workgroup per queued bucket: lanes take the bucket's slices round-robin, then an LDS tree
-template <class Cv>
+template <class Cv, bool RAW>
 __global__ __launch_bounds__(256) void k_msm_fixup_heavy(const uint32_t* __restrict__ off, uint32_t L,
                                                          const uint32_t* __restrict__ partA,
                                                          const uint32_t* __restrict__ partB,
@@ -715,9 +728,9 @@ __global__ __launch_bounds__(256) void k_msm_fixup_heavy(const uint32_t* __restr
         const uint32_t s = off[b], e = off[b + 1];
         const uint32_t t1 = s / L, t2 = (e - 1) / L;
         XYZZ<Cv> acc = XYZZ<Cv>::identity();
-        if (threadIdx.x == 0) acc = xyzz_load<Cv>(((s % L == 0) ? partA : partB) + (size_t)t1 * XZ);
+        if (threadIdx.x == 0) acc = elem_load<Cv, RAW>((s % L == 0) ? partA : partB, t1);
         for (uint32_t t = t1 + 1 + threadIdx.x; t <= t2; t += 256u) {
-            XYZZ<Cv> q = xyzz_load<Cv>(partA + (size_t)t * XZ);
+            XYZZ<Cv> q = elem_load<Cv, RAW>(partA, t);
             xyzz_add_inl<Cv>(acc, q);
         }
         xyzz_store<Cv>(sh + threadIdx.x * XZ, acc);
@@ -745,9 +758,14 @@ JF_DEV XYZZ<Cv> xyzz_mul_small(const XYZZ<Cv>& p, uint32_t k) {
     return r;
 }
 
-// lane t folds buckets [t*g, (t+1)*g): V_t = sum_j (t*g + j + 1) * B[t*g + j]
-template <class Cv>
-__global__ __launch_bounds__(64) void k_msm_bucket_fold(const uint32_t* __restrict__ buckets, uint32_t B, uint32_t g,
+// lane t folds buckets [t*g, (t+1)*g): V_t = sum_j (t*g + j + 1) * B[t*g + j].  A bucket that spans slices was summed
+// by the fix-up into `fixed` (saturated); every other one is where the accumulation left it (`acc_buckets`, RAW: the
+// 29-bit kernel's form, converted here -- independent of the running-sum chain, so it costs this latency-bound kernel
+// little).
+template <class Cv, bool RAW>
+__global__ __launch_bounds__(64) void k_msm_bucket_fold(const uint32_t* __restrict__ fixed,
+                                                        const uint32_t* __restrict__ acc_buckets,
+                                                        const uint32_t* __restrict__ off, uint32_t L, uint32_t B, uint32_t g,
                                                         uint32_t* __restrict__ out) {
     constexpr int XZ = 4 * Cv::Fq::N;
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -755,7 +773,9 @@ __global__ __launch_bounds__(64) void k_msm_bucket_fold(const uint32_t* __restri
     uint32_t lo = t * g, hi = (lo + g < B) ? lo + g : B;
     XYZZ<Cv> run = XYZZ<Cv>::identity(), sum = XYZZ<Cv>::identity();
     for (uint32_t j = hi; j-- > lo;) {
-        XYZZ<Cv> q = xyzz_load<Cv>(buckets + (size_t)j * XZ);
+        const uint32_t s = off[j], e = off[j + 1];
+        const bool spans = e > s && s / L != (e - 1) / L;
+        XYZZ<Cv> q = spans ? xyzz_load<Cv>(fixed + (size_t)j * XZ) : elem_load<Cv, RAW>(acc_buckets, j);
         xyzz_add_inl<Cv>(run, q);
         xyzz_add_inl<Cv>(sum, run);
     }
@@ -1342,7 +1362,6 @@ static int32_t msm_partial_t(const jfhip_srs* srs, size_t offset, const uint32_t
     uint2* entries = st->dig.as<uint2>();
 
     JF_HIP(hipMemsetAsync(counts, 0, ((size_t)nb + 1) * 4, st->s));
-    JF_HIP(hipMemsetAsync(buckets, 0, (size_t)B * XZ * 4, st->s));
     const uint32_t tile_scalars = env_tile >= 256 ? (uint32_t)(env_tile / 256 * 256) : (uint32_t)SORT_TILE_SCALARS;
     const unsigned tiles = (unsigned)((n + tile_scalars - 1) / tile_scalars);
     hipLaunchKernelGGL((k_msm_coarse<Cv, 0>), dim3(tiles), dim3(256), 0, st->s, d_scalars, (uint32_t)n, pl, tile_scalars,
@@ -1399,6 +1418,9 @@ static int32_t msm_partial_t(const jfhip_srs* srs, size_t offset, const uint32_t
                            st->sorted.as<uint32_t>());
     }
     pt.mark();
+    JF_TRY(st->heavy.ensure((T / HEAVY_SPAN + 4) * 4));
+    JF_HIP(hipMemsetAsync(st->heavy.p, 0, 4, st->s));
+    uint32_t* fold = st->partA.as<uint32_t>();
     if (srs->f29) {
         const int occ = f29_occ;
         auto kern = occ == 2 ? k_msm_accumulate29<Cv, 2> : occ == 3 ? k_msm_accumulate29<Cv, 3> : k_msm_accumulate29<Cv, 4>;
@@ -1406,30 +1428,38 @@ static int32_t msm_partial_t(const jfhip_srs* srs, size_t offset, const uint32_t
         const size_t elems = (size_t)B + 2 * T;
         JF_TRY(st->raw29.ensure(elems * XR * 4));
         uint32_t* raw = st->raw29.as<uint32_t>();
+        uint32_t* rawA = raw + (size_t)B * XR;
+        uint32_t* rawB = raw + ((size_t)B + T) * XR;
         JF_HIP(hipMemsetAsync(raw, 0, (size_t)B * XR * 4, st->s));  // untouched buckets are the identity
-        hipLaunchKernelGGL(kern, dim3((unsigned)((T + 127) / 128)), dim3(128), 0, st->s,
-                           st->sorted.as<uint32_t>(), offs, B, srs->table, (uint32_t)L, raw, raw + (size_t)B * XR,
-                           raw + ((size_t)B + T) * XR);
-        hipLaunchKernelGGL((k_xyzz29_to_std<Cv>), dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, st->s, raw, B,
-                           (uint32_t)T, buckets, st->partA.as<uint32_t>(), st->partB.as<uint32_t>());
-    } else
+        hipLaunchKernelGGL(kern, dim3((unsigned)((T + 127) / 128)), dim3(128), 0, st->s, st->sorted.as<uint32_t>(), offs,
+                           B, srs->table, (uint32_t)L, raw, rawA, rawB);
+        pt.mark();
+        // the runs stay in the accumulation's raw form: the fix-up and the fold convert the elements they read
+        hipLaunchKernelGGL((k_msm_fixup<Cv, true>), dim3((B + 127) / 128), dim3(128), 0, st->s, offs, B, (uint32_t)L, rawA,
+                           rawB, buckets, st->heavy.as<uint32_t>());
+        hipLaunchKernelGGL((k_msm_fixup_heavy<Cv, true>), dim3(1024), dim3(256), 0, st->s, offs, (uint32_t)L, rawA, rawB,
+                           buckets, st->heavy.as<uint32_t>());
+        pt.mark();
+        hipLaunchKernelGGL((k_msm_bucket_fold<Cv, true>), dim3((Tf + 63) / 64), dim3(64), 0, st->s, buckets, raw, offs,
+                           (uint32_t)L, B, g, fold);
+    } else {
+        JF_HIP(hipMemsetAsync(buckets, 0, (size_t)B * XZ * 4, st->s));
         hipLaunchKernelGGL((k_msm_accumulate<Cv>), dim3((unsigned)((T + 127) / 128)), dim3(128), 0, st->s,
                            st->sorted.as<uint32_t>(), offs, B, srs->table, (uint32_t)L, buckets,
                            st->partA.as<uint32_t>(), st->partB.as<uint32_t>());
-    pt.mark();
-    JF_TRY(st->heavy.ensure((T / HEAVY_SPAN + 4) * 4));
-    JF_HIP(hipMemsetAsync(st->heavy.p, 0, 4, st->s));
-    hipLaunchKernelGGL((k_msm_fixup<Cv>), dim3((B + 127) / 128), dim3(128), 0, st->s, offs, B, (uint32_t)L,
-                       st->partA.as<uint32_t>(), st->partB.as<uint32_t>(), buckets, st->heavy.as<uint32_t>());
-    hipLaunchKernelGGL((k_msm_fixup_heavy<Cv>), dim3(1024), dim3(256), 0, st->s, offs, (uint32_t)L,
-                       st->partA.as<uint32_t>(), st->partB.as<uint32_t>(), buckets, st->heavy.as<uint32_t>());
-    pt.mark();
-    DevBuf& fold = st->partA;  // partA is free again after the fix-up
-    hipLaunchKernelGGL((k_msm_bucket_fold<Cv>), dim3((Tf + 63) / 64), dim3(64), 0, st->s, buckets, B, g,
-                       fold.as<uint32_t>());
+        pt.mark();
+        hipLaunchKernelGGL((k_msm_fixup<Cv, false>), dim3((B + 127) / 128), dim3(128), 0, st->s, offs, B, (uint32_t)L,
+                           st->partA.as<uint32_t>(), st->partB.as<uint32_t>(), buckets, st->heavy.as<uint32_t>());
+        hipLaunchKernelGGL((k_msm_fixup_heavy<Cv, false>), dim3(1024), dim3(256), 0, st->s, offs, (uint32_t)L,
+                           st->partA.as<uint32_t>(), st->partB.as<uint32_t>(), buckets, st->heavy.as<uint32_t>());
+        pt.mark();
+        // partA is free again after the fix-up
+        hipLaunchKernelGGL((k_msm_bucket_fold<Cv, false>), dim3((Tf + 63) / 64), dim3(64), 0, st->s, buckets, buckets, offs,
+                           (uint32_t)L, B, g, fold);
+    }
     JF_HIP(hipGetLastError());
     pt.mark();
-    JF_TRY(g1_sum_xyzz_t<Cv>(fold.as<uint32_t>(), Tf, d_out_xyzz, st));
+    JF_TRY(g1_sum_xyzz_t<Cv>(fold, Tf, d_out_xyzz, st));
     pt.mark();
     pt.finish();
     return JFHIP_OK;
