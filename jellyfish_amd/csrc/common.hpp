@@ -129,7 +129,7 @@ struct jfhip_stream {
     bool owned = false;
     std::mutex mu;  // one MSM/NTT at a time per stream object (workspace is per stream)
     // MSM workspace
-    jf::DevBuf scalars, dig, dig2, sorted, counts, offs, cursor, bsum, midbase, midcnt, midcur, finecnt, finecur, buckets, partA, partB, red0, red1, result, raw29, heavy;
+    jf::DevBuf scalars, dig, dig2, sorted, counts, offs, cursor, bsum, midbase, midcnt, midcur, finecnt, finecur, buckets, partA, partB, red0, red1, result, raw29, heavy, tilehist, tilebase;
     // NTT workspace
     jf::DevBuf ntt_tmp, ntt_io;
     // open()
@@ -143,7 +143,7 @@ struct jfhip_stream {
     template <class F>
     void for_each_buf(F f) {
         jf::DevBuf* all[] = {&scalars, &dig, &dig2, &sorted, &counts, &offs, &cursor, &bsum, &midbase, &midcnt, &midcur,
-                             &finecnt, &finecur, &buckets, &partA, &partB, &red0, &red1, &result, &raw29, &heavy,
+                             &finecnt, &finecur, &buckets, &partA, &partB, &red0, &red1, &result, &raw29, &heavy, &tilehist, &tilebase,
                              &ntt_tmp, &ntt_io, &poly_a, &poly_b, &poly_c, &quot_consts};
         for (jf::DevBuf* b : all) f(b);
     }

@@ -74,7 +74,8 @@ JF_DEV int32_t signed_digit(const uint32_t (&v)[N], int w, int c, uint32_t& carr
     return (int32_t)raw;
 }
 
-// PASS = 0: coarse histogram only.  PASS = 1: reserve + scatter entries.
+// PASS = 0: coarse histogram only.  PASS = 1: reserve + scatter entries.  PASS = 2: per-tile histogram (for
+// k_msm_coarse_staged).
 template <class Cv, int PASS>
 __global__ __launch_bounds__(256) void k_msm_coarse(const uint32_t* __restrict__ scalars, uint32_t n, DigitPlan pl,
                                                     uint32_t tile_scalars, uint32_t table_n, uint32_t offset,
@@ -107,6 +108,10 @@ __global__ __launch_bounds__(256) void k_msm_coarse(const uint32_t* __restrict__
     if (PASS == 0) {
         for (uint32_t k = threadIdx.x; k < nb; k += 256)
             if (hist[k]) atomicAdd(&gcount[k], hist[k]);
+        return;
+    }
+    if (PASS == 2) {   // histogram of this tile, [bin][tile] layout: its exclusive scan is every tile's offset in every bin
+        for (uint32_t k = threadIdx.x; k < nb; k += 256) gcount[(size_t)k * gridDim.x + blockIdx.x] = hist[k];
         return;
     }
     for (uint32_t k = threadIdx.x; k < nb; k += 256) {
@@ -236,6 +241,199 @@ __global__ __launch_bounds__(LVL_THREADS) void k_msm_level(const uint2* __restri
     }
 }
 
+// ---- staged scatters: a chunk is counting-sorted in LDS first, then copied out in runs ------------
+//
+// The direct scatters above store one 8-byte entry per lane to as many different places as the level has keys; with a
+// span per (workgroup, key) the store frontiers of the resident workgroups do not fit the L2, so the lines go out
+// partially written (k_msm_coarse<1> at 2^24: 2.1 GB moved in 2.14 ms, 68 % of the wave cycles waiting on memory).
+// Here a workgroup ranks the entries of its chunk by key into 32 KiB of LDS and copies the staged array out in order:
+// consecutive lanes store consecutive entries of one key's reserved span (runs of chunk / keys entries).  Every entry
+// is read from global memory once and kept in registers between the counting and the ranking pass.
+constexpr int STG_CAP = 4096;    // staged entries per flush: 32 KiB, four workgroups per CU
+constexpr int STG_KEYS = 1024;   // LDS counters per flush (level kernels; the coarse level has <= 512 bins)
+constexpr int STG_PER = STG_CAP / 256;
+
+// cur[k] (counts on entry) -> start of key k inside the staged array; delta[k] = (span reserved in g[k]) - that start.
+// Every lane of the 256-lane workgroup calls this; returns the number of staged entries.
+// GLOBAL_G: g[] are global cursors shared by all workgroups (atomic reservation); otherwise g[] is owned by this
+// workgroup (LDS) and key k is always handled by the same lane.
+template <bool GLOBAL_G>
+JF_DEV uint32_t stage_scan_reserve(uint32_t* cur, uint32_t* delta, uint32_t* wsum, uint32_t nkeys, uint32_t* g) {
+    const uint32_t t = threadIdx.x, k0 = 4 * t, lane = t & 63u;
+    uint32_t v[4], s = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        v[i] = (k0 + i < nkeys) ? cur[k0 + i] : 0u;
+        s += v[i];
+    }
+    uint32_t inc = s;
+#pragma unroll
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) wsum[t >> 6] = inc;
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t w = 0; w < (t >> 6); w++) base += wsum[w];
+    const uint32_t total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    uint32_t loc = base + inc - s;
+    uint32_t gpos[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        if constexpr (GLOBAL_G) gpos[i] = (k0 + i < nkeys && v[i]) ? atomicAdd(&g[k0 + i], v[i]) : 0u;
+        else {
+            gpos[i] = 0;
+            if (k0 + i < nkeys) {
+                gpos[i] = g[k0 + i];
+                g[k0 + i] = gpos[i] + v[i];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        if (k0 + i < nkeys) {
+            cur[k0 + i] = loc;
+            delta[k0 + i] = gpos[i] - loc;
+            loc += v[i];
+        }
+    }
+    __syncthreads();
+    return total;
+}
+
+// largest s in [0, nseg) with segbase[s] <= pos, by 64-way probes (three dependent loads for 2^18 segments instead of
+// the eighteen of a binary search); all lanes of the wave return the same value.  Requires segbase[0] <= pos.
+JF_DEV uint32_t seg_search64(const uint32_t* __restrict__ segbase, uint32_t nseg, uint32_t pos) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t lo = 0, len = nseg;   // answer in [lo, lo + len)
+    while (len > 1) {
+        const uint32_t step = (len + 63u) >> 6;
+        const uint32_t idx = lo + lane * step;
+        const bool le = idx < lo + len && segbase[idx] <= pos;
+        const uint32_t cnt = (uint32_t)__popcll(__ballot(le));   // >= 1: lane 0 probes segbase[lo] <= pos
+        const uint32_t nlo = lo + (cnt - 1u) * step;
+        const uint32_t nlen = (nlo + step < lo + len) ? step : lo + len - nlo;
+        lo = nlo;
+        len = nlen;
+    }
+    return lo;
+}
+
+// k_msm_coarse<Cv, 1> with staging: 256 scalars (<= STG_CAP entries, W <= 16) per flush, digits kept in registers
+template <class Cv>
+__global__ __launch_bounds__(256) void k_msm_coarse_staged(const uint32_t* __restrict__ scalars, uint32_t n, DigitPlan pl,
+                                                           uint32_t tile_scalars, uint32_t table_n, uint32_t offset,
+                                                           const uint32_t* __restrict__ tile_base /*[bin][tile]*/,
+                                                           uint2* __restrict__ entries) {
+    using Fr = typename Cv::Fr;
+    __shared__ uint2 stage[STG_CAP];
+    __shared__ uint32_t cur[512], delta[512], tcur[512], wsum[4];
+    const uint32_t nb = 1u << pl.coarse_bits;
+    // where this tile's entries of every bin go: exclusive scan of the [bin][tile] histogram (k_msm_coarse<Cv, 2>).  No
+    // atomics: with one global cursor per bin every flush of every workgroup queues on the same <= 512 addresses
+    // (measured ~80 ns per same-address atomic: 65536 flushes = 4.9 ms at 2^24).
+    for (uint32_t k = threadIdx.x; k < nb; k += 256) tcur[k] = tile_base[(size_t)k * gridDim.x + blockIdx.x];
+    const uint32_t tile0 = blockIdx.x * tile_scalars;
+    const uint32_t tile1 = (tile0 + tile_scalars < n) ? tile0 + tile_scalars : n;
+    for (uint32_t f0 = tile0; f0 < tile1; f0 += 256u) {
+        const uint32_t i = f0 + threadIdx.x;
+        // digit w as bucket | sign << 31, 0xffffffff = none
+        uint32_t dg[16];
+#pragma unroll
+        for (int w = 0; w < 16; w++) dg[w] = 0xffffffffu;
+        if (i < tile1) {
+            Fp<Fr> s = fp_from_mont<Fr>(fp_load<Fr>(scalars + (size_t)i * Fr::N));
+            uint32_t carry = 0;
+#pragma unroll
+            for (int w = 0; w < 16; w++) {
+                if (w < pl.W) {
+                    int32_t d = signed_digit<Fr::N>(s.v, w, pl.c, carry);
+                    if (d != 0) dg[w] = ((uint32_t)(d < 0 ? -d : d) - 1u) | (d < 0 ? 0x80000000u : 0u);
+                }
+            }
+        }
+        for (uint32_t k = threadIdx.x; k < nb; k += 256) cur[k] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < 16; w++)
+            if (dg[w] != 0xffffffffu) atomicAdd(&cur[(dg[w] & 0x7fffffffu) >> pl.fine_bits], 1u);
+        __syncthreads();
+        const uint32_t m = stage_scan_reserve<false>(cur, delta, wsum, nb, tcur);
+#pragma unroll
+        for (int w = 0; w < 16; w++) {
+            if (dg[w] != 0xffffffffu) {
+                const uint32_t b = dg[w] & 0x7fffffffu;
+                const uint32_t payload = ((uint32_t)w * table_n + offset + i) | (dg[w] & 0x80000000u);
+                stage[atomicAdd(&cur[b >> pl.fine_bits], 1u)] = make_uint2(payload, b);
+            }
+        }
+        __syncthreads();
+        for (uint32_t e = threadIdx.x; e < m; e += 256) {
+            const uint2 en = stage[e];
+            entries[delta[en.y >> pl.fine_bits] + e] = en;
+        }
+        __syncthreads();
+    }
+}
+
+// k_msm_level<1 / 2> with staging (MODE 1: entries out, MODE 2: final payloads out); chunks of STG_CAP entries
+template <int MODE>
+__global__ __launch_bounds__(256) void k_msm_level_staged(const uint2* __restrict__ in,
+                                                          const uint32_t* __restrict__ segbase, uint32_t nseg, int shift,
+                                                          int bits, uint32_t* __restrict__ gcursor,
+                                                          uint2* __restrict__ out_entries,
+                                                          uint32_t* __restrict__ out_sorted) {
+    __shared__ uint2 stage[STG_CAP];
+    __shared__ uint32_t cur[STG_KEYS], delta[STG_KEYS], wsum[4];
+    const uint32_t total = segbase[nseg];
+    const uint64_t c0_64 = (uint64_t)blockIdx.x * STG_CAP;
+    if (c0_64 >= total) return;
+    const uint32_t c0 = (uint32_t)c0_64;
+    const uint32_t c1 = (uint32_t)((c0_64 + STG_CAP < total) ? c0_64 + STG_CAP : total);
+    const uint32_t seg_per_group = (uint32_t)STG_KEYS >> bits;
+    // the chunk, read once: register k of lane t is entry c0 + k * 256 + t
+    uint2 ent[STG_PER];
+#pragma unroll
+    for (int k = 0; k < STG_PER; k++) {
+        const uint32_t e = c0 + k * 256u + threadIdx.x;
+        ent[k] = e < c1 ? in[e] : make_uint2(0u, 0u);
+    }
+    uint32_t pos = c0;
+    while (pos < c1) {
+        // the segment that holds entry `pos`: empty stretches of segments are never walked
+        const uint32_t s0 = seg_search64(segbase, nseg, pos);
+        const uint32_t s1 = (s0 + seg_per_group < nseg) ? s0 + seg_per_group : nseg;
+        uint32_t e_hi = segbase[s1];   // > pos: s1 > s0 and segment s0 holds pos
+        if (e_hi > c1) e_hi = c1;
+        const uint32_t nkeys = (s1 - s0) << bits;
+        const uint32_t key0 = s0 << bits;
+        for (uint32_t k = threadIdx.x; k < nkeys; k += 256) cur[k] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < STG_PER; k++) {
+            const uint32_t e = c0 + k * 256u + threadIdx.x;
+            if (e >= pos && e < e_hi) atomicAdd(&cur[(ent[k].y >> shift) - key0], 1u);
+        }
+        __syncthreads();
+        const uint32_t m = stage_scan_reserve<true>(cur, delta, wsum, nkeys, gcursor + ((size_t)s0 << bits));
+#pragma unroll
+        for (int k = 0; k < STG_PER; k++) {
+            const uint32_t e = c0 + k * 256u + threadIdx.x;
+            if (e >= pos && e < e_hi) stage[atomicAdd(&cur[(ent[k].y >> shift) - key0], 1u)] = ent[k];
+        }
+        __syncthreads();
+        for (uint32_t e = threadIdx.x; e < m; e += 256) {
+            const uint2 en = stage[e];
+            const uint32_t at = delta[(en.y >> shift) - key0] + e;
+            if (MODE == 2) out_sorted[at] = en.x;
+            else out_entries[at] = en;
+        }
+        __syncthreads();
+        pos = e_hi;
+    }
+}
+
 // ---- exclusive scan of up to 2^24 counters (3 small launches) ---------------------------------
 constexpr int SCAN_ITEMS = 8;
 constexpr int SCAN_BLOCK = 256;
@@ -301,7 +499,17 @@ __global__ __launch_bounds__(256) void k_scan_add(uint32_t* __restrict__ off, ui
     if (i >= n) return;
     uint32_t v = off[i] + bsum[i / (SCAN_BLOCK * SCAN_ITEMS)];
     off[i] = v;
-    cursor[i] = v;
+    if (cursor) cursor[i] = v;
+}
+
+// coarse segment bases from the scanned [bin][tile] histogram: cbase[k] = scanned[k * tiles], cbase[nb] = total = off[B]
+__global__ __launch_bounds__(256) void k_msm_coarse_bases(const uint32_t* __restrict__ scanned, uint32_t nb, uint32_t tiles,
+                                                          uint32_t* __restrict__ cbase, uint32_t* __restrict__ off_total) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > nb) return;
+    const uint32_t v = scanned[(size_t)k * tiles];
+    cbase[k] = v;
+    if (k == nb) *off_total = v;
 }
 
 // Advance (b, b_lo, b_hi) to the bucket that holds sorted position `pos` (pos >= b_hi on entry).  The next bucket is
@@ -1327,17 +1535,27 @@ static int32_t msm_partial_t(const jfhip_srs* srs, size_t offset, const uint32_t
     DigitPlan pl;
     pl.c = c;
     pl.W = W;
-    pl.coarse_bits = (c - 1) - 8;
+    // bucket id bits are consumed in levels of <= 9 bits (staged scatters: runs of >= 16 entries per key and chunk)
+    static const bool staged = !(getenv("JFHIP_MSM_SORT") && getenv("JFHIP_MSM_SORT")[0] == '0');
     static const int env_cb = getenv("JFHIP_MSM_COARSE_BITS") ? atoi(getenv("JFHIP_MSM_COARSE_BITS")) : -1;
     static const int env_tile = getenv("JFHIP_MSM_TILE") ? atoi(getenv("JFHIP_MSM_TILE")) : 0;
+    const int level_max = staged ? 9 : 8;
+    if (staged) {
+        const int nlev = (c - 1 + 8) / 9;
+        pl.coarse_bits = (c - 1 + nlev - 1) / nlev;
+    } else {
+        pl.coarse_bits = (c - 1) - 8;
+        if (pl.coarse_bits > MAX_COARSE_BITS) pl.coarse_bits = MAX_COARSE_BITS;
+    }
     if (env_cb >= 0 && env_cb < pl.coarse_bits) pl.coarse_bits = env_cb;
     if (pl.coarse_bits < 0) pl.coarse_bits = 0;
-    if (pl.coarse_bits > MAX_COARSE_BITS) pl.coarse_bits = MAX_COARSE_BITS;
     pl.fine_bits = (c - 1) - pl.coarse_bits;
     if (pl.fine_bits > MAX_FINE_BITS) {
         set_error("window_bits %d unsupported by the bucket sort (max %d)", c, MAX_COARSE_BITS + MAX_FINE_BITS + 1);
         return JFHIP_ERR_INVALID;
     }
+    // a flush stages the <= 16 digits of 256 scalars; more windows than that (c < 16, small MSMs): direct scatter
+    const bool staged_coarse = staged && W <= 16;
     const uint32_t nb = 1u << pl.coarse_bits;
 
     JF_TRY(st->dig.ensure(total_max * 8));     // level-1 entries (payload, fine bucket)
@@ -1361,33 +1579,60 @@ static int32_t msm_partial_t(const jfhip_srs* srs, size_t offset, const uint32_t
     uint32_t* buckets = st->buckets.as<uint32_t>();
     uint2* entries = st->dig.as<uint2>();
 
-    JF_HIP(hipMemsetAsync(counts, 0, ((size_t)nb + 1) * 4, st->s));
+    auto scan = [&](uint32_t* cnts, uint32_t m, uint32_t* out_base, uint32_t* out_cursor) -> int32_t {
+        // out_base[0..m] = exclusive scan (out_base[m] = total), out_cursor (optional) = copy of out_base[0..m)
+        const uint32_t nblk = (m + SCAN_BLOCK * SCAN_ITEMS - 1) / (SCAN_BLOCK * SCAN_ITEMS);
+        JF_TRY(st->red0.ensure((size_t)nblk * 4));
+        uint32_t* bs = st->red0.as<uint32_t>();
+        hipLaunchKernelGGL(k_scan_local, dim3(nblk), dim3(SCAN_BLOCK), 0, st->s, cnts, m, out_base, bs);
+        hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(SCAN_BLOCK), 0, st->s, bs, nblk, out_base + m);
+        hipLaunchKernelGGL(k_scan_add, dim3((m + 255) / 256), dim3(256), 0, st->s, out_base, m, bs, out_cursor);
+        return JFHIP_OK;
+    };
     const uint32_t tile_scalars = env_tile >= 256 ? (uint32_t)(env_tile / 256 * 256) : (uint32_t)SORT_TILE_SCALARS;
     const unsigned tiles = (unsigned)((n + tile_scalars - 1) / tile_scalars);
-    hipLaunchKernelGGL((k_msm_coarse<Cv, 0>), dim3(tiles), dim3(256), 0, st->s, d_scalars, (uint32_t)n, pl, tile_scalars,
-                       (uint32_t)srs->n, (uint32_t)offset, counts, entries);
-    hipLaunchKernelGGL(k_msm_coarse_scan, dim3(1), dim3(1024), 0, st->s, counts, nb, cbase, cursor, offs + B);
-    pt.mark();
-    hipLaunchKernelGGL((k_msm_coarse<Cv, 1>), dim3(tiles), dim3(256), 0, st->s, d_scalars, (uint32_t)n, pl, tile_scalars,
-                       (uint32_t)srs->n, (uint32_t)offset, cursor, entries);
+    if (staged_coarse) {
+        // per-tile histograms in [bin][tile] order; their exclusive scan places every tile in every coarse bin
+        const size_t m = (size_t)nb * tiles;
+        JF_TRY(st->tilehist.ensure((m + 1) * 4));
+        JF_TRY(st->tilebase.ensure((m + 1) * 4));
+        hipLaunchKernelGGL((k_msm_coarse<Cv, 2>), dim3(tiles), dim3(256), 0, st->s, d_scalars, (uint32_t)n, pl,
+                           tile_scalars, (uint32_t)srs->n, (uint32_t)offset, st->tilehist.as<uint32_t>(), entries);
+        JF_TRY(scan(st->tilehist.as<uint32_t>(), (uint32_t)m, st->tilebase.as<uint32_t>(), (uint32_t*)nullptr));
+        hipLaunchKernelGGL(k_msm_coarse_bases, dim3((nb + 256) / 256), dim3(256), 0, st->s, st->tilebase.as<uint32_t>(), nb,
+                           tiles, cbase, offs + B);
+        pt.mark();
+        hipLaunchKernelGGL((k_msm_coarse_staged<Cv>), dim3(tiles), dim3(256), 0, st->s, d_scalars, (uint32_t)n, pl,
+                           tile_scalars, (uint32_t)srs->n, (uint32_t)offset, st->tilebase.as<uint32_t>(), entries);
+    } else {
+        JF_HIP(hipMemsetAsync(counts, 0, ((size_t)nb + 1) * 4, st->s));
+        hipLaunchKernelGGL((k_msm_coarse<Cv, 0>), dim3(tiles), dim3(256), 0, st->s, d_scalars, (uint32_t)n, pl,
+                           tile_scalars, (uint32_t)srs->n, (uint32_t)offset, counts, entries);
+        hipLaunchKernelGGL(k_msm_coarse_scan, dim3(1), dim3(1024), 0, st->s, counts, nb, cbase, cursor, offs + B);
+        pt.mark();
+        hipLaunchKernelGGL((k_msm_coarse<Cv, 1>), dim3(tiles), dim3(256), 0, st->s, d_scalars, (uint32_t)n, pl,
+                           tile_scalars, (uint32_t)srs->n, (uint32_t)offset, cursor, entries);
+    }
     {
-        // refinement levels over the fine bits: one level if <= 8 bits, else two
+        // refinement levels over the fine bits: one level if it fits, else two
         const unsigned chunks = (unsigned)((total_max + LVL_CHUNK - 1) / LVL_CHUNK);
-        auto scan = [&](uint32_t* cnts, uint32_t m, uint32_t* out_base, uint32_t* out_cursor) -> int32_t {
-            // out_base[0..m] = exclusive scan (out_base[m] = total), out_cursor = copy of out_base[0..m)
-            const uint32_t nblk = (m + SCAN_BLOCK * SCAN_ITEMS - 1) / (SCAN_BLOCK * SCAN_ITEMS);
-            JF_TRY(st->red0.ensure((size_t)nblk * 4));
-            uint32_t* bs = st->red0.as<uint32_t>();
-            hipLaunchKernelGGL(k_scan_local, dim3(nblk), dim3(SCAN_BLOCK), 0, st->s, cnts, m, out_base, bs);
-            hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(SCAN_BLOCK), 0, st->s, bs, nblk, out_base + m);
-            hipLaunchKernelGGL(k_scan_add, dim3((m + 255) / 256), dim3(256), 0, st->s, out_base, m, bs, out_cursor);
-            return JFHIP_OK;
+        auto scatter = [&](bool final, const uint2* in, const uint32_t* segbase, uint32_t nseg, int shift, int bits,
+                           uint32_t* cur, uint2* out_e, uint32_t* out_s) {
+            const dim3 grid(staged ? (unsigned)((total_max + STG_CAP - 1) / STG_CAP) : chunks), block(LVL_THREADS);
+            if (staged && final)
+                hipLaunchKernelGGL((k_msm_level_staged<2>), grid, block, 0, st->s, in, segbase, nseg, shift, bits, cur, out_e, out_s);
+            else if (staged)
+                hipLaunchKernelGGL((k_msm_level_staged<1>), grid, block, 0, st->s, in, segbase, nseg, shift, bits, cur, out_e, out_s);
+            else if (final)
+                hipLaunchKernelGGL((k_msm_level<2>), grid, block, 0, st->s, in, segbase, nseg, shift, bits, cur, out_e, out_s);
+            else
+                hipLaunchKernelGGL((k_msm_level<1>), grid, block, 0, st->s, in, segbase, nseg, shift, bits, cur, out_e, out_s);
         };
         const uint2* cur_entries = entries;
         const uint32_t* cur_base = cbase;
         uint32_t cur_nseg = nb;
         int rem = pl.fine_bits;
-        if (rem > 8) {
+        if (rem > level_max) {
             const int lo_bits = rem / 2, hi_bits = rem - lo_bits;
             const uint32_t nmid = nb << hi_bits;
             JF_TRY(st->midbase.ensure(((size_t)nmid + 1) * 4));
@@ -1399,9 +1644,8 @@ static int32_t msm_partial_t(const jfhip_srs* srs, size_t offset, const uint32_t
                                cur_nseg, lo_bits, hi_bits, st->midcnt.as<uint32_t>(), (uint2*)nullptr,
                                (uint32_t*)nullptr);
             JF_TRY(scan(st->midcnt.as<uint32_t>(), nmid, st->midbase.as<uint32_t>(), st->midcur.as<uint32_t>()));
-            hipLaunchKernelGGL((k_msm_level<1>), dim3(chunks), dim3(LVL_THREADS), 0, st->s, cur_entries, cur_base,
-                               cur_nseg, lo_bits, hi_bits, st->midcur.as<uint32_t>(), st->dig2.as<uint2>(),
-                               (uint32_t*)nullptr);
+            scatter(false, cur_entries, cur_base, cur_nseg, lo_bits, hi_bits, st->midcur.as<uint32_t>(),
+                    st->dig2.as<uint2>(), (uint32_t*)nullptr);
             cur_entries = st->dig2.as<uint2>();
             cur_base = st->midbase.as<uint32_t>();
             cur_nseg = nmid;
@@ -1413,9 +1657,8 @@ static int32_t msm_partial_t(const jfhip_srs* srs, size_t offset, const uint32_t
         hipLaunchKernelGGL((k_msm_level<0>), dim3(chunks), dim3(LVL_THREADS), 0, st->s, cur_entries, cur_base,
                            cur_nseg, 0, rem, st->finecnt.as<uint32_t>(), (uint2*)nullptr, (uint32_t*)nullptr);
         JF_TRY(scan(st->finecnt.as<uint32_t>(), B, offs, st->finecur.as<uint32_t>()));
-        hipLaunchKernelGGL((k_msm_level<2>), dim3(chunks), dim3(LVL_THREADS), 0, st->s, cur_entries, cur_base,
-                           cur_nseg, 0, rem, st->finecur.as<uint32_t>(), (uint2*)nullptr,
-                           st->sorted.as<uint32_t>());
+        scatter(true, cur_entries, cur_base, cur_nseg, 0, rem, st->finecur.as<uint32_t>(), (uint2*)nullptr,
+                st->sorted.as<uint32_t>());
     }
     pt.mark();
     JF_TRY(st->heavy.ensure((T / HEAVY_SPAN + 4) * 4));

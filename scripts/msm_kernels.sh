@@ -10,7 +10,7 @@ import sqlite3, sys
 c = sqlite3.connect(sys.argv[1])
 rows = c.execute("select name, start, end from kernels order by start").fetchall()
 # the last MSM = kernels after the last k_msm_coarse<..., 0>
-last = max(i for i, r in enumerate(rows) if "k_msm_coarse" in r[0] and ", 0>" in r[0])
+last = max(i for i, r in enumerate(rows) if "k_msm_coarse<" in r[0] and (", 0>" in r[0] or ", 2>" in r[0]))
 t0 = rows[last][1]
 for nm, s, e in rows[last - 2:]:
     print("%8.3f ms  +%7.3f  %s" % ((s - t0) / 1e6, (e - s) / 1e6, nm[:90]))
