@@ -815,6 +815,67 @@ def unshard_quotient(cp, curve: int, gathered: torch.Tensor, m: int, out: torch.
                               stream=stream)
 
 
+QUOTIENT_SLICES = True   # False: evaluate the quotient on all m = 8 n points like the reference (bench comparison; same results)
+
+
+def quotient_slices(n: int, m: int, ncoeffs: int) -> list:
+    """disjoint slices (g, G) -- the points i = g (mod G) of the quotient coset, m / G of them -- with at least ncoeffs
+    points in total: i even (4 n points), i = 1 (mod 4) (2 n), i = 3 (mod 8) (n) as far as needed; [(0, 1)] when that does
+    not apply (ratio other than 8, tiny domains)"""
+    if m != 8 * n or n < 16:
+        return [(0, 1)]
+    out, have = [], 0
+    for g, G in ((0, 2), (1, 4), (3, 8)):
+        out.append((g, G))
+        have += m // G
+        if have >= ncoeffs:
+            return out
+    return [(0, 1)]
+
+
+def unslice_matrix(cp, m: int, slices) -> tuple:
+    """t(X) = sum_k X^(k s) t_k in chunks of s = the smallest slice size.  Slice j (q_j s points, offset o_j) holds
+    t mod (X^(q_j s) - c_j), c_j = o_j^(q_j s): its chunk e is sum over k = e (mod q_j) of c_j^((k - e) / q_j) t_k.  Returns
+    (s, inverse of that square matrix over Fr): t_k = sum_(j, e) inv[k][(j, e)] * (chunk e of slice j)."""
+    r = cp.r
+    sizes = [m // G for _, G in slices]
+    s = min(sizes)
+    qs = [sz // s for sz in sizes]
+    K = sum(qs)
+    rows = []
+    for (g, G), q in zip(slices, qs):
+        cj = pow(slice_offset(cp, m, g), q * s, r)
+        for e in range(q):
+            rows.append([pow(cj, (k - e) // q, r) if k % q == e else 0 for k in range(K)])
+    # Gauss-Jordan over Fr (K <= 7)
+    a = [row[:] + [1 if i == j else 0 for j in range(K)] for i, row in enumerate(rows)]
+    for col in range(K):
+        piv = next(i for i in range(col, K) if a[i][col])
+        a[col], a[piv] = a[piv], a[col]
+        inv = pow(a[col][col], -1, r)
+        a[col] = [x * inv % r for x in a[col]]
+        for i in range(K):
+            if i != col and a[i][col]:
+                f = a[i][col]
+                a[i] = [(x - f * y) % r for x, y in zip(a[i], a[col])]
+    return s, [row[K:] for row in a]
+
+
+def unslice_quotient(cp, curve: int, parts, slices, m: int, stream) -> torch.Tensor:
+    """quotient coefficients (m entries, zero beyond the slices' total) from the slice polynomials: K lincombs of <= K terms"""
+    s, inv = unslice_matrix(cp, m, slices)
+    ptrs = []
+    for part in parts:
+        ptrs += [part.data_ptr() + e * s * 32 for e in range(part.shape[0] // (4 * s))]
+    K = len(ptrs)
+    out = torch.zeros(m * 4, dtype=torch.int64, device="cuda")
+    for k in range(K):
+        terms = [(ptrs[j], inv[k][j]) for j in range(K) if inv[k][j]]
+        L.poly_lincomb_device(curve, [t[0] for t in terms], [s] * len(terms), H.fr_to_mont(cp, [t[1] for t in terms]),
+                              out.data_ptr() + k * s * 32, s, stream=stream)
+    return out
+
+
 def _row_ids(rows: torch.Tensor) -> torch.Tensor:
     """equal rows (4 x int64) -> equal ids: one 64-bit radix sort of a mixing key instead of a lexicographic sort of the
     256-bit rows (torch.unique(dim=0): 80 ms for 2^23 rows).  Exact: rows are compared in full between sorted neighbours,
@@ -1300,80 +1361,97 @@ class PlonkKzgSnark:
             g = tdist.get_rank(group)
             if not coset_sharding_applies(n, m, G):
                 G, g = 1, 0
-        ml = m // G
-        log_ml = ml.bit_length() - 1
-        off_int = slice_offset(cp, m, g)
-        off = mont([off_int])[0]
-        lc4 = min(l4, ml * 4)
-        quot = torch.zeros(m * 4, dtype=torch.int64, device="cuda")
-        part = torch.zeros(ml * 4, dtype=torch.int64, device="cuda") if G > 1 else None
-        for i in mine:
-            pk, vk, wire_polys, perm_poly = prove_keys[i], vks[i], wire_polys_v[i], perm_poly_v[i]
-            NSEL = pk.selectors.shape[0]
-            nlk = 7 if lookup[i] else 0
-            if pk.coset_evals is not None:
-                # selector / sigma (/ table) coset evaluations are resident with the proving key
-                fixed = pk.coset_evals
-                if fixed.shape != (NSEL + W + (4 if lookup[i] else 0), ml * 4) or pk.coset_slice != (g, G):
-                    raise PlonkError("proving key coset evaluations were kept for another slice of the quotient coset")
-                npolys, o_w = W + 2 + nlk, 0
-                sel_ptr, sig_ptr = fixed[0].data_ptr(), fixed[NSEL].data_ptr()
-            else:
-                npolys, o_w = NSEL + 2 * W + 2 + nlk, NSEL + W
-            o_z, o_pi, o_lk = o_w + W, o_w + W + 1, o_w + W + 2
-            cs = torch.empty(npolys, ml * 4, dtype=torch.int64, device="cuda")
-            cs[:, n4:lc4].zero_()
-            if pk.coset_evals is None:
-                cs[:NSEL, :n4].copy_(pk.selectors)
-                cs[NSEL:o_w, :n4].copy_(pk.sigmas)
-                sel_ptr, sig_ptr = cs[0].data_ptr(), cs[NSEL].data_ptr()
-            cs[o_w:o_z, :lc4].copy_(wire_polys[:, :lc4])
-            cs[o_z, :lc4].copy_(perm_poly[:lc4])
-            cs[o_pi, :n4].copy_(pub_poly_v[i])
-            online = [wire_polys[j] for j in range(W)] + [perm_poly]      # polynomials of n + 2 / n + 3 coefficients
-            online_rows = list(range(o_w, o_z + 1))
-            if lookup[i]:
-                # the quotient kernel's Plookup rows: range_table, key_table, table_dom_sep, q_dom_sep, h_1, h_2, prod_lookup
+        def slice_quotient(g, G):
+            """sum_i alpha_base_i t_i evaluated on the slice i = g (mod G) of the quotient coset (a coset of ml = m / G
+            points with offset h w_m^g), transformed back: the coefficients of t(X) mod (X^ml - (h w_m^g)^ml)"""
+            ml = m // G
+            log_ml = ml.bit_length() - 1
+            off_int = slice_offset(cp, m, g)
+            off = mont([off_int])[0]
+            lc4 = min(l4, ml * 4)
+            out = torch.zeros(ml * 4, dtype=torch.int64, device="cuda")
+            for i in mine:
+                pk, vk, wire_polys, perm_poly = prove_keys[i], vks[i], wire_polys_v[i], perm_poly_v[i]
+                NSEL = pk.selectors.shape[0]
+                nlk = 7 if lookup[i] else 0
+                if pk.coset_evals is not None:
+                    # selector / sigma (/ table) coset evaluations are resident with the proving key
+                    fixed = pk.coset_evals
+                    if fixed.shape != (NSEL + W + (4 if lookup[i] else 0), ml * 4) or pk.coset_slice != (g, G):
+                        raise PlonkError("proving key coset evaluations were kept for another slice of the quotient coset")
+                    npolys, o_w = W + 2 + nlk, 0
+                    sel_ptr, sig_ptr = fixed[0].data_ptr(), fixed[NSEL].data_ptr()
+                else:
+                    npolys, o_w = NSEL + 2 * W + 2 + nlk, NSEL + W
+                o_z, o_pi, o_lk = o_w + W, o_w + W + 1, o_w + W + 2
+                cs = torch.empty(npolys, ml * 4, dtype=torch.int64, device="cuda")
+                cs[:, n4:lc4].zero_()
                 if pk.coset_evals is None:
-                    cs[o_lk:o_lk + 4, :n4].copy_(pk.plookup_polys)
-                cs[o_lk + 4:o_lk + 6, :lc4].copy_(h_polys_v[i][:, :lc4])
-                cs[o_lk + 6, :lc4].copy_(pl_poly_v[i][:lc4])
-                online += [h_polys_v[i][0], h_polys_v[i][1], pl_poly_v[i]]
-                online_rows += [o_lk + 4, o_lk + 5, o_lk + 6]
-            if lc4 < l4:
-                # ml = n < n + 3 coefficients: reduce mod X^ml - off^ml (the slice's vanishing polynomial)
-                fold = mont([1, pow(off_int, ml, r)])
-                k = (l4 - lc4) // 4
-                tmp = torch.empty(len(online), k * 4, dtype=torch.int64, device="cuda")
-                for j, poly in enumerate(online):
-                    L.poly_lincomb_device(c, [poly.data_ptr(), poly.data_ptr() + lc4 * 8], [k, k], fold,
-                                          tmp[j].data_ptr(), k, stream=st)
-                for j, row in enumerate(online_rows):
-                    cs[row, :k * 4].copy_(tmp[j])
-            # identically-zero polynomials: no transform, and the quotient kernel is told not to read their rows
-            zmask = sum(1 << j for j, z in enumerate(pk.selector_is_zero) if z) if SKIP_ZERO_POLYS else 0
-            pi_zero = SKIP_ZERO_POLYS and not pub_inputs[i]
-            zero_rows = [o_pi] if pi_zero else []
-            if pk.coset_evals is None:
-                zero_rows += [j for j in range(NSEL) if (zmask >> j) & 1]
-            elif lookup[i]:
-                zero_rows += list(range(o_lk, o_lk + 4))          # resident: copied below, not transformed
-            _coset_ntt_rows(c, cs, zero_rows, log_ml, off, lc4 // 4, st)
-            if pk.coset_evals is not None and lookup[i]:
-                cs[o_lk:o_lk + 4].copy_(pk.coset_evals[NSEL + W:])
-            tick("r3_coset_ntts")
-            chal = mont([alpha, beta, gamma] + ([tau] if lookup[i] else []) + [alpha_bases[i]])
-            # G == 1: the slice is the whole quotient coset (offset Fr::GENERATOR, log_ml = log_m)
-            L.plonk_quotient_masked_device(c, W, log_n, log_ml, off, sel_ptr, sig_ptr, cs[o_w].data_ptr(),
-                                           cs[o_z].data_ptr(), 0 if pi_zero else cs[o_pi].data_ptr(),
-                                           cs[o_lk].data_ptr() if lookup[i] else 0, mont(vk.k), chal,
-                                           zmask, (quot if G == 1 else part).data_ptr(), stream=st)
-            del cs                             # stream-ordered: the next allocation is used on the same stream
-            tick("r3_quotient_intt")
-        if G == 1:
-            L.ntt_device(c, quot.data_ptr(), log_m, 1, inverse=True, coset_mont=gen, stream=st)
+                    cs[:NSEL, :n4].copy_(pk.selectors)
+                    cs[NSEL:o_w, :n4].copy_(pk.sigmas)
+                    sel_ptr, sig_ptr = cs[0].data_ptr(), cs[NSEL].data_ptr()
+                cs[o_w:o_z, :lc4].copy_(wire_polys[:, :lc4])
+                cs[o_z, :lc4].copy_(perm_poly[:lc4])
+                cs[o_pi, :n4].copy_(pub_poly_v[i])
+                online = [wire_polys[j] for j in range(W)] + [perm_poly]      # polynomials of n + 2 / n + 3 coefficients
+                online_rows = list(range(o_w, o_z + 1))
+                if lookup[i]:
+                    # the quotient kernel's Plookup rows: range_table, key_table, table_dom_sep, q_dom_sep, h_1, h_2, prod_lookup
+                    if pk.coset_evals is None:
+                        cs[o_lk:o_lk + 4, :n4].copy_(pk.plookup_polys)
+                    cs[o_lk + 4:o_lk + 6, :lc4].copy_(h_polys_v[i][:, :lc4])
+                    cs[o_lk + 6, :lc4].copy_(pl_poly_v[i][:lc4])
+                    online += [h_polys_v[i][0], h_polys_v[i][1], pl_poly_v[i]]
+                    online_rows += [o_lk + 4, o_lk + 5, o_lk + 6]
+                if lc4 < l4:
+                    # ml = n < n + 3 coefficients: reduce mod X^ml - off^ml (the slice's vanishing polynomial)
+                    fold = mont([1, pow(off_int, ml, r)])
+                    k = (l4 - lc4) // 4
+                    tmp = torch.empty(len(online), k * 4, dtype=torch.int64, device="cuda")
+                    for j, poly in enumerate(online):
+                        L.poly_lincomb_device(c, [poly.data_ptr(), poly.data_ptr() + lc4 * 8], [k, k], fold,
+                                              tmp[j].data_ptr(), k, stream=st)
+                    for j, row in enumerate(online_rows):
+                        cs[row, :k * 4].copy_(tmp[j])
+                # identically-zero polynomials: no transform, and the quotient kernel is told not to read their rows
+                zmask = sum(1 << j for j, z in enumerate(pk.selector_is_zero) if z) if SKIP_ZERO_POLYS else 0
+                pi_zero = SKIP_ZERO_POLYS and not pub_inputs[i]
+                zero_rows = [o_pi] if pi_zero else []
+                if pk.coset_evals is None:
+                    zero_rows += [j for j in range(NSEL) if (zmask >> j) & 1]
+                elif lookup[i]:
+                    zero_rows += list(range(o_lk, o_lk + 4))          # resident: copied below, not transformed
+                _coset_ntt_rows(c, cs, zero_rows, log_ml, off, lc4 // 4, st)
+                if pk.coset_evals is not None and lookup[i]:
+                    cs[o_lk:o_lk + 4].copy_(pk.coset_evals[NSEL + W:])
+                tick("r3_coset_ntts")
+                chal = mont([alpha, beta, gamma] + ([tau] if lookup[i] else []) + [alpha_bases[i]])
+                # G == 1: the slice is the whole quotient coset (offset Fr::GENERATOR, log_ml = log_m)
+                L.plonk_quotient_masked_device(c, W, log_n, log_ml, off, sel_ptr, sig_ptr, cs[o_w].data_ptr(),
+                                               cs[o_z].data_ptr(), 0 if pi_zero else cs[o_pi].data_ptr(),
+                                               cs[o_lk].data_ptr() if lookup[i] else 0, mont(vk.k), chal,
+                                               zmask, out.data_ptr(), stream=st)
+                del cs                             # stream-ordered: the next allocation is used on the same stream
+                tick("r3_quotient_intt")
+            L.ntt_device(c, out.data_ptr(), log_ml, 1, inverse=True, coset_mont=off, stream=st)
+            return out
+
+        ml = m // G
+        expected_degree = W * (n + 1) + 2
+        # One GPU: the quotient has expected_degree + 1 <= W (n + 2) coefficients, fewer than the m = 8 n points the
+        # reference evaluates (prover.rs:524-527).  Disjoint slices of the same coset -- 4 n + 2 n points for TurboPlonk,
+        # 4 n + 2 n + n for UltraPlonk -- determine it as well (unslice_quotient): 6 / 8 (7 / 8) of the coset transforms
+        # and of the quotient kernel's points, same polynomial, same proof bytes.
+        slices = [(g, G)]
+        if G == 1 and QUOTIENT_SLICES and all(prove_keys[i].coset_evals is None for i in mine):
+            slices = quotient_slices(n, m, expected_degree + 1)
+        if len(slices) > 1:
+            quot = unslice_quotient(cp, c, [slice_quotient(gg, GG) for gg, GG in slices], slices, m, st)
+        elif G == 1:
+            quot = slice_quotient(0, 1)
         else:
-            L.ntt_device(c, part.data_ptr(), log_ml, 1, inverse=True, coset_mont=off, stream=st)
+            part = slice_quotient(g, G)
+            quot = torch.zeros(m * 4, dtype=torch.int64, device="cuda")
             st.sync()
             if tdist.get_backend(group) == "gloo":
                 host = torch.empty(G * ml * 4, dtype=torch.int64)
@@ -1386,7 +1464,6 @@ class PlonkKzgSnark:
                 gathered = gathered.view(G, ml * 4)
             unshard_quotient(cp, c, gathered, m, quot, st)
         tick("r3_quotient_intt")
-        expected_degree = W * (n + 1) + 2
         # the split randomisers (prover.rs:926-940) are drawn while the device still works on the quotient: the next RNG
         # draws in the reference's order whether or not the degree check below passes
         randomizers = draw(W - 1)
