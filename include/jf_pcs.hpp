@@ -11,6 +11,7 @@
 //     load_batch_poly_to_gpu, commit_on_gpu, load_commitments_to_host
 //   warmup_new_stream                                      pcs/src/lib.rs:430-435
 //   PCSError::{InvalidParameters, UpstreamError}           pcs/src/errors.rs:19-34
+//   MultilinearKzgPCS::{commit, open}                     pcs/src/multilinear_kzg/mod.rs:123-149,180-186,288-358
 //   Radix2EvaluationDomain::{fft, ifft, fft_in_place, ifft_in_place, get_coset}  (ark-poly 0.5),
 //     as called at plonk/src/proof_system/prover.rs:524-573,658-660 and
 //     relation/src/constraint_system.rs:1369-1622
@@ -425,6 +426,107 @@ class UnivariateKzgPCS {
         return *c;
     }
     // icicle_projective_to_ark (:982-998): identity -> G1Affine::zero()
+    static G1Affine<E> to_affine(const uint64_t* xy, uint8_t inf) {
+        if (inf) return G1Affine<E>::zero();
+        G1Affine<E> p;
+        std::memcpy(p.x.data(), xy, sizeof(p.x));
+        std::memcpy(p.y.data(), xy + E::FQ_LIMBS, sizeof(p.y));
+        p.infinity = false;
+        return p;
+    }
+};
+
+// ---- multilinear KZG: the MSM sites of pcs/src/multilinear_kzg/mod.rs ---------------------------------
+// MultilinearProverParam { num_vars, powers_of_g: Vec<Evaluations> } (pcs/src/multilinear_kzg/srs.rs:20-33):
+// powers_of_g[i].evals holds 2^(num_vars - i) points, powers_of_g[num_vars] = [g].
+template <class E>
+struct MultilinearProverParam {
+    size_t num_vars = 0;
+    std::vector<std::vector<G1Affine<E>>> powers_of_g;
+};
+// ark_poly::DenseMultilinearExtension: evaluations over {0,1}^num_vars, variable 0 = lowest index bit
+struct DenseMultilinearExtension {
+    size_t num_vars = 0;
+    std::vector<Fr> evaluations;
+};
+template <class E>
+struct MultilinearKzgProof {  // pcs/src/multilinear_kzg/mod.rs:46-50
+    std::vector<G1Affine<E>> proofs;
+};
+
+template <class E>
+class MultilinearKzgPCS {
+   public:
+    using Polynomial = DenseMultilinearExtension;
+    using Point = std::vector<Fr>;
+    using Evaluation = Fr;
+
+    // device copy of every level of the prover parameter (one window table per level)
+    struct DeviceParam {
+        size_t num_vars = 0;
+        std::vector<DeviceSrs<E>> levels;
+    };
+    static Result<std::shared_ptr<DeviceParam>> load_prover_param_to_gpu(const MultilinearProverParam<E>& pp) {
+        auto d = std::make_shared<DeviceParam>();
+        d->num_vars = pp.num_vars;
+        for (const auto& lvl : pp.powers_of_g) {
+            std::vector<uint64_t> packed(lvl.size() * 2 * E::FQ_LIMBS, 0);
+            for (size_t i = 0; i < lvl.size(); i++) {
+                if (lvl[i].infinity) continue;
+                std::memcpy(&packed[i * 2 * E::FQ_LIMBS], lvl[i].x.data(), sizeof(lvl[i].x));
+                std::memcpy(&packed[i * 2 * E::FQ_LIMBS + E::FQ_LIMBS], lvl[i].y.data(), sizeof(lvl[i].y));
+            }
+            jfhip_srs* h = nullptr;
+            int32_t rc = jfhip_srs_load(E::ID, packed.data(), lvl.size(), 16 * E::FQ_LIMBS, 0, &h);
+            if (rc) return last_error(rc);
+            d->levels.emplace_back(h);
+        }
+        return d;
+    }
+
+    // commit (mod.rs:123-149): msm over powers_of_g[ignored].evals
+    static Result<Commitment<E>> commit(const DeviceParam& pp, const Polynomial& poly) {
+        if (pp.num_vars < poly.num_vars)
+            return PCSError{PCSError::InvalidParameters, "Poly length (" + std::to_string(poly.num_vars) +
+                                                             ") exceeds param limit (" + std::to_string(pp.num_vars) + ")"};
+        if (poly.evaluations.size() != ((size_t)1 << poly.num_vars))
+            return PCSError{PCSError::InvalidParameters, "evaluation table is not 2^num_vars long"};
+        const size_t ignored = pp.num_vars - poly.num_vars;
+        uint64_t xy[2 * E::FQ_LIMBS];
+        uint8_t inf = 0;
+        int32_t rc = jfhip_msm(pp.levels[ignored].get(), 0, poly.evaluations[0].data(), poly.evaluations.size(), xy, &inf,
+                               nullptr);
+        if (rc) return last_error(rc);
+        return Commitment<E>{to_affine(xy, inf)};
+    }
+
+    // open (mod.rs:180-186 -> open_internal :288-358)
+    static Result<std::pair<MultilinearKzgProof<E>, Evaluation>> open(const DeviceParam& pp, const Polynomial& poly,
+                                                                      const Point& point) {
+        if (poly.num_vars > pp.num_vars)
+            return PCSError{PCSError::InvalidParameters, "Polynomial num_vars " + std::to_string(poly.num_vars) +
+                                                             " exceed the limit " + std::to_string(pp.num_vars)};
+        if (poly.num_vars != point.size())
+            return PCSError{PCSError::InvalidParameters, "Polynomial num_vars " + std::to_string(poly.num_vars) +
+                                                             " does not match point len " + std::to_string(point.size())};
+        if (poly.evaluations.size() != ((size_t)1 << poly.num_vars))
+            return PCSError{PCSError::InvalidParameters, "evaluation table is not 2^num_vars long"};
+        const size_t nv = poly.num_vars;
+        const size_t ignored = pp.num_vars - nv + 1;
+        std::vector<const jfhip_srs*> lv(nv);
+        for (size_t i = 0; i < nv; i++) lv[i] = pp.levels[ignored + i].get();
+        std::vector<uint64_t> xy(nv * 2 * E::FQ_LIMBS + 1);
+        std::vector<uint8_t> inf(nv + 1);
+        Fr eval{};
+        int32_t rc = jfhip_mle_open(lv.data(), nv, poly.evaluations[0].data(), nv ? point[0].data() : nullptr, xy.data(),
+                                    inf.data(), eval.data(), nullptr);
+        if (rc) return last_error(rc);
+        MultilinearKzgProof<E> proof;
+        for (size_t i = 0; i < nv; i++) proof.proofs.push_back(to_affine(&xy[i * 2 * E::FQ_LIMBS], inf[i]));
+        return std::make_pair(std::move(proof), eval);
+    }
+
+   private:
     static G1Affine<E> to_affine(const uint64_t* xy, uint8_t inf) {
         if (inf) return G1Affine<E>::zero();
         G1Affine<E> p;

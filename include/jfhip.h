@@ -178,6 +178,25 @@ int32_t jfhip_g1_sum_partials(int32_t curve_id, const void *d_partials_xyzz, siz
 int32_t jfhip_kzg_open(const jfhip_srs *srs, const uint64_t *coeffs_mont, size_t n, const uint64_t *point_mont,
                        void *out_proof_xy, uint8_t *out_infinity, uint64_t *out_eval_mont, jfhip_stream *stream);
 
+/* ---- Multilinear KZG --------------------------------------------------- */
+
+/* MultilinearKzgPCS::commit / batch_commit (pcs/src/multilinear_kzg/mod.rs:123-174) are
+ * E::G1::msm_bigint(&prover_param.0.powers_of_g[ignored].evals, evaluations).into_affine(): load that level's `evals`
+ * with jfhip_srs_load and call jfhip_msm / jfhip_msm_device on the evaluation table -- no entry point of their own.
+ *
+ * Replaces open_internal (pcs/src/multilinear_kzg/mod.rs:288-358): nv rounds over the evaluation table,
+ *   q[b] = f[2b + 1] - f[2b],  r[b] = f[2b] + q[b] * point[i],  proofs[i] = msm(levels[i], q),  f = r,
+ * on the device.  levels[i]: handle of prover_param.powers_of_g[ignored + i].evals (>= 2^(nv - 1 - i) points;
+ * ignored = prover_param.num_vars - nv + 1, :317).  evals_mont: 2^nv Fr values (host, Montgomery), point_mont: nv Fr
+ * values.  out_proofs_xy / out_infinity: nv packed affine points and flags; *out_eval_mont = f(point), the value
+ * `polynomial.evaluate(point)` of :355.  nv == 0 writes the evaluation only. */
+int32_t jfhip_mle_open(const jfhip_srs *const *levels, size_t nv, const uint64_t *evals_mont, const uint64_t *point_mont,
+                       void *out_proofs_xy, uint8_t *out_infinity, uint64_t *out_eval_mont, jfhip_stream *stream);
+/* One such round on DEVICE memory (mod.rs:330-338), asynchronous on `stream`: d_f holds 2 * half values, d_q and d_r
+ * receive half values each (d_r may not alias d_f). */
+int32_t jfhip_mle_fold_device(int32_t curve_id, const void *d_f, size_t half, const uint64_t *point_mont, void *d_q,
+                              void *d_r, jfhip_stream *stream);
+
 /* ---- NTT ---------------------------------------------------------------------------------- */
 
 /* Replaces Radix2EvaluationDomain::{fft, ifft, ifft_in_place} and get_coset(offset).{fft,ifft}

@@ -746,6 +746,81 @@ int32_t jfhip_kzg_open(const jfhip_srs* srs, const uint64_t* coeffs, size_t n, c
     return JFHIP_OK;
 }
 
+// ---- multilinear KZG (the MSM sites of pcs/src/multilinear_kzg/mod.rs) --------------
+
+int32_t jfhip_mle_fold_device(int32_t curve_id, const void* d_f, size_t half, const uint64_t* point, void* d_q, void* d_r,
+                              jfhip_stream* stream) {
+    JF_TRY(check_curve(curve_id));
+    if (!point || (half && (!d_f || !d_q || !d_r))) {
+        set_error("null argument");
+        return JFHIP_ERR_INVALID;
+    }
+    JF_STREAM(st, stream);
+    std::lock_guard<std::mutex> lk(st->mu);
+    JF_TRY(st->quot_consts.ensure(32));
+    JF_HIP(hipMemcpyAsync(st->quot_consts.p, point, 32, hipMemcpyHostToDevice, st->s));
+    return mle_fold_device(curve_id, (const uint32_t*)d_f, half, st->quot_consts.as<uint32_t>(), (uint32_t*)d_q,
+                           (uint32_t*)d_r, st);
+}
+
+int32_t jfhip_mle_open(const jfhip_srs* const* levels, size_t nv, const uint64_t* evals, const uint64_t* point,
+                       void* out_xy, uint8_t* out_inf, uint64_t* out_eval, jfhip_stream* stream) {
+    if (!evals || !out_eval || (nv && (!levels || !point || !out_xy || !out_inf))) {
+        set_error("null argument");
+        return JFHIP_ERR_INVALID;
+    }
+    if (nv > 30) {
+        set_error("mle open: %zu variables unsupported (max 30)", nv);
+        return JFHIP_ERR_INVALID;
+    }
+    if (nv == 0) {
+        memcpy(out_eval, evals, 32);
+        return JFHIP_OK;
+    }
+    const int32_t curve = levels[0] ? levels[0]->curve : -1;
+    for (size_t i = 0; i < nv; i++) {
+        if (!levels[i] || levels[i]->curve != curve) {
+            set_error("mle open: null or mixed-curve SRS level %zu", i);
+            return JFHIP_ERR_INVALID;
+        }
+        // round i commits 2^(nv - 1 - i) values against powers_of_g[ignored + i].evals (mod.rs:322-350)
+        JF_TRY(check_msm_range(levels[i], 0, (size_t)1 << (nv - 1 - i)));
+    }
+    JF_STREAM(st, stream);
+    std::lock_guard<std::mutex> lk(st->mu);
+    const size_t n = (size_t)1 << nv;
+    const size_t pt = 2 * (size_t)fq_bytes(curve);
+    const size_t rec = (pt + 4 + 15) & ~(size_t)15;
+    JF_TRY(st->poly_a.ensure(n * 32));          // f
+    JF_TRY(st->poly_b.ensure(n * 16 + 32));      // r (next f), ping-pong with f
+    JF_TRY(st->poly_c.ensure(n * 16 + 32));      // q
+    JF_TRY(st->quot_consts.ensure(nv * 32));
+    JF_TRY(st->ntt_io.ensure(nv * rec));
+    JF_HIP(hipMemcpyAsync(st->poly_a.p, evals, n * 32, hipMemcpyHostToDevice, st->s));
+    JF_HIP(hipMemcpyAsync(st->quot_consts.p, point, nv * 32, hipMemcpyHostToDevice, st->s));
+    uint32_t* f = st->poly_a.as<uint32_t>();
+    uint32_t* r = st->poly_b.as<uint32_t>();
+    for (size_t i = 0; i < nv; i++) {
+        const size_t half = (size_t)1 << (nv - 1 - i);
+        JF_TRY(mle_fold_device(curve, f, half, st->quot_consts.as<uint32_t>() + i * 8, st->poly_c.as<uint32_t>(), r, st));
+        JF_TRY(msm_device_locked(levels[i], 0, st->poly_c.p, half, st->ntt_io.as<uint8_t>() + i * rec, st));
+        uint32_t* t = f;
+        f = r;
+        r = t;
+    }
+    std::vector<uint8_t> host(nv * rec);
+    JF_HIP(hipMemcpyAsync(host.data(), st->ntt_io.p, nv * rec, hipMemcpyDeviceToHost, st->s));
+    JF_HIP(hipMemcpyAsync(out_eval, f, 32, hipMemcpyDeviceToHost, st->s));   // the table folded to one value: f(point)
+    JF_HIP(hipStreamSynchronize(st->s));
+    for (size_t i = 0; i < nv; i++) {
+        memcpy((uint8_t*)out_xy + i * pt, host.data() + i * rec, pt);
+        uint32_t inf;
+        memcpy(&inf, host.data() + i * rec + pt, 4);
+        out_inf[i] = inf ? 1 : 0;
+    }
+    return JFHIP_OK;
+}
+
 // ---- NTT ----------------------------------------------------------------------------------------
 
 int32_t jfhip_ntt_device(int32_t curve_id, void* d_data, uint32_t log_n, size_t batch, int32_t inverse,

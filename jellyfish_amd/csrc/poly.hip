@@ -356,6 +356,39 @@ int32_t poly_lincomb_device(int32_t curve, const uint32_t* const* d_polys, const
     return JFHIP_OK;
 }
 
+// ---- multilinear fold (MultilinearKzgPCS::open, pcs/src/multilinear_kzg/mod.rs:330-338) ------------
+// One round of open_internal on the evaluation table: q[b] = f[2b + 1] - f[2b], r[b] = f[2b] + q[b] * p, b < half.
+// Lane b reads the adjacent pair (64 B) and writes two elements: a streaming pass, 128 B and one product per lane.
+template <class Fr>
+__global__ __launch_bounds__(256) void k_mle_fold(const uint32_t* __restrict__ f, uint32_t half,
+                                                  const uint32_t* __restrict__ point, uint32_t* __restrict__ q,
+                                                  uint32_t* __restrict__ r) {
+    constexpr int N = Fr::N;
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= half) return;
+    const Fp<Fr> f0 = fp_load<Fr>(f + (size_t)(2 * (size_t)b) * N);
+    const Fp<Fr> f1 = fp_load<Fr>(f + (size_t)(2 * (size_t)b + 1) * N);
+    const Fp<Fr> d = fp_sub<Fr>(f1, f0);
+    fp_store<Fr>(q + (size_t)b * N, d);
+    fp_store<Fr>(r + (size_t)b * N, fp_add<Fr>(f0, fp_mul<Fr>(d, fp_load<Fr>(point))));
+}
+
+int32_t mle_fold_device(int32_t curve, const uint32_t* d_f, size_t half, const uint32_t* d_point, uint32_t* d_q,
+                        uint32_t* d_r, jfhip_stream* st) {
+    if (half == 0) return JFHIP_OK;
+    if (half >= ((size_t)1 << 31)) {
+        set_error("mle fold: table too long");
+        return JFHIP_ERR_INVALID;
+    }
+    dim3 grid((unsigned)((half + 255) / 256));
+    if (curve == JFHIP_BN254)
+        hipLaunchKernelGGL((k_mle_fold<Bn254Fr>), grid, dim3(256), 0, st->s, d_f, (uint32_t)half, d_point, d_q, d_r);
+    else
+        hipLaunchKernelGGL((k_mle_fold<Bls381Fr>), grid, dim3(256), 0, st->s, d_f, (uint32_t)half, d_point, d_q, d_r);
+    JF_HIP(hipGetLastError());
+    return JFHIP_OK;
+}
+
 // ---- element-wise field ops (test surface) ------------------------------------------------------
 template <class C>
 __global__ __launch_bounds__(128) void k_field_op(int op, const uint32_t* __restrict__ a,

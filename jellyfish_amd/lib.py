@@ -36,7 +36,7 @@ SYMBOLS = [
     "jfhip_srs_load_serialized", "jfhip_msm_small",
     "jfhip_srs_gen_for_testing", "jfhip_srs_free", "jfhip_srs_len", "jfhip_srs_window_bits", "jfhip_srs_read",
     "jfhip_msm", "jfhip_msm_batch", "jfhip_msm_batch_device", "jfhip_msm_device", "jfhip_msm_partial_device", "jfhip_g1_sum_partials",
-    "jfhip_kzg_open", "jfhip_ntt", "jfhip_ntt_device", "jfhip_plonk_quotient_turbo_device", "jfhip_plonk_quotient_ultra_device", "jfhip_plonk_quotient_coset_device", "jfhip_plonk_quotient_masked_device", "jfhip_plonk_perm_product_device", "jfhip_plonk_lookup_product_device", "jfhip_plonk_lookup_merge_device", "jfhip_witness_gather_device", "jfhip_poly_divide_linear_device", "jfhip_poly_divide_linear_noalloc_device",
+    "jfhip_kzg_open", "jfhip_mle_open", "jfhip_mle_fold_device", "jfhip_ntt", "jfhip_ntt_device", "jfhip_plonk_quotient_turbo_device", "jfhip_plonk_quotient_ultra_device", "jfhip_plonk_quotient_coset_device", "jfhip_plonk_quotient_masked_device", "jfhip_plonk_perm_product_device", "jfhip_plonk_lookup_product_device", "jfhip_plonk_lookup_merge_device", "jfhip_witness_gather_device", "jfhip_poly_divide_linear_device", "jfhip_poly_divide_linear_noalloc_device",
     "jfhip_poly_lincomb_device", "jfhip_poly_eval_batch_device", "jfhip_field_op", "jfhip_g1_op", "jfhip_probe",
     "jfhip_set_profiling", "jfhip_last_phase_ms", "jfhip_phase_name", "jfhip_keccak_f1600",
 ]
@@ -280,6 +280,29 @@ def kzg_open(srs: Srs, coeffs_mont, point_mont, stream: Stream | None = None):
     _check(load_library().jfhip_kzg_open(srs.h, _p(c) if n else None, ctypes.c_size_t(n), _p(z), _p(out),
                                          ctypes.byref(inf), _p(ev), _sh(stream)))
     return out, bool(inf.value), ev
+
+
+def mle_open(levels, evals_mont, point_mont, stream: Stream | None = None):
+    """MultilinearKzgPCS::open (open_internal): levels[i] = Srs of powers_of_g[ignored + i].evals.
+    -> (proofs (nv, 2 * fq limbs) packed affine, identity flags (nv,), eval limbs)"""
+    ev, pt = _u64(evals_mont), _u64(point_mont)
+    nv = len(levels)
+    if ev.size != 4 << nv or pt.size != 4 * nv:
+        raise ValueError("evaluation table must hold 2^nv values and the point nv values")
+    curve = levels[0].curve if nv else 0
+    out = np.zeros((nv, 2 * FQ_LIMBS64[curve]), dtype=np.uint64)
+    inf = np.zeros(nv, dtype=np.uint8)
+    val = np.zeros(4, dtype=np.uint64)
+    hs = (ctypes.c_void_p * max(nv, 1))(*[lv.h for lv in levels])
+    _check(load_library().jfhip_mle_open(hs, ctypes.c_size_t(nv), _p(ev), _p(pt) if nv else None, _p(out) if nv else None,
+                                         _p(inf) if nv else None, _p(val), _sh(stream)))
+    return out, inf.astype(bool), val
+
+
+def mle_fold_device(curve: int, d_f: int, half: int, point_mont, d_q: int, d_r: int, stream: Stream | None = None):
+    z = _u64(point_mont)
+    _check(load_library().jfhip_mle_fold_device(curve, _vp(d_f), ctypes.c_size_t(half), _p(z), _vp(d_q), _vp(d_r),
+                                                _sh(stream)))
 
 
 def ntt(curve: int, data, log_n: int, inverse: bool = False, coset_mont=None, in_len: int = 0,

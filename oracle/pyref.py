@@ -256,6 +256,63 @@ def srs_powers(cv: Curve, beta: int, g, n: int):
 
 
 # ----------------------------------------------------------------------------------
+# Multilinear KZG (pcs/src/multilinear_kzg): test SRS, commit, open
+# ----------------------------------------------------------------------------------
+
+
+def mle_eq_levels(cv: Curve, t):
+    """scalars of MultilinearProverParam::powers_of_g (tests::gen_srs_for_testing, pcs/src/multilinear_kzg/srs.rs:
+    299-358): level i holds eq_(t[i..])(x) for x in {0,1}^(nv - i), x's bit j standing for variable i + j; the last
+    level is [1] (the generator itself).  eq factor of one variable: t x + (1 - t)(1 - x) (eq_extension, :280-297)."""
+    r = cv.fr.p
+    nv = len(t)
+    levels = []
+    for i in range(nv):
+        vals = [1]
+        for tj in t[i:]:                              # variable i first = lowest bit
+            vals = [v * f % r for f in ((1 - tj) % r, tj % r) for v in vals]
+        levels.append(vals)
+    levels.append([1])
+    return levels
+
+
+def mle_srs_for_testing(cv: Curve, g, t):
+    """powers_of_g[i].evals = g * eq level i"""
+    return [[ec_mul(cv, e, g) for e in lvl] for lvl in mle_eq_levels(cv, t)]
+
+
+def mle_evaluate(cv: Curve, evals, point) -> int:
+    """DenseMultilinearExtension::evaluate: fix variable 0 (lowest index bit) first"""
+    r = cv.fr.p
+    f = list(evals)
+    for z in point:
+        f = [(f[2 * b] + (f[2 * b + 1] - f[2 * b]) * z) % r for b in range(len(f) // 2)]
+    return f[0]
+
+
+def mle_commit(cv: Curve, powers_of_g, num_vars: int, evals):
+    """MultilinearKzgPCS::commit (pcs/src/multilinear_kzg/mod.rs:123-149)"""
+    nv = len(evals).bit_length() - 1
+    return msm_naive(cv, powers_of_g[num_vars - nv], evals)
+
+
+def mle_open(cv: Curve, powers_of_g, num_vars: int, evals, point):
+    """open_internal (pcs/src/multilinear_kzg/mod.rs:288-358) -> (proofs, evaluation)"""
+    r = cv.fr.p
+    nv = len(point)
+    assert len(evals) == 1 << nv
+    ignored = num_vars - nv + 1
+    f = [e % r for e in evals]
+    proofs = []
+    for i, z in enumerate(point):
+        k = nv - 1 - i
+        q = [(f[2 * b + 1] - f[2 * b]) % r for b in range(1 << k)]
+        f = [(f[2 * b] + q[b] * z) % r for b in range(1 << k)]
+        proofs.append(msm_naive(cv, powers_of_g[ignored + i], q))
+    return proofs, mle_evaluate(cv, evals, point)
+
+
+# ----------------------------------------------------------------------------------
 # KZG on top (commit / open), restating pcs/src/univariate_kzg/mod.rs:90-180
 # ----------------------------------------------------------------------------------
 

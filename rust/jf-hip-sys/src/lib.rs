@@ -153,6 +153,25 @@ extern "C" {
         out_eval_mont: *mut u64,
         stream: *mut jfhip_stream,
     ) -> i32;
+    pub fn jfhip_mle_open(
+        levels: *const *const jfhip_srs,
+        nv: usize,
+        evals_mont: *const u64,
+        point_mont: *const u64,
+        out_proofs_xy: *mut c_void,
+        out_infinity: *mut u8,
+        out_eval_mont: *mut u64,
+        stream: *mut jfhip_stream,
+    ) -> i32;
+    pub fn jfhip_mle_fold_device(
+        curve_id: i32,
+        d_f: *const c_void,
+        half: usize,
+        point_mont: *const u64,
+        d_q: *mut c_void,
+        d_r: *mut c_void,
+        stream: *mut jfhip_stream,
+    ) -> i32;
 
     // ---- NTT ----
     pub fn jfhip_ntt(

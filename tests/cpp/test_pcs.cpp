@@ -15,6 +15,7 @@ int jfo_msm(int curve, const uint64_t* bases, const uint64_t* scalars_mont, size
 int jfo_open_witness(int curve, const uint64_t* coeffs, size_t n, const uint64_t* z, uint64_t* q_out, uint64_t* eval_out);
 int jfo_ntt(int curve, uint64_t* data, int log_n, size_t batch, int inverse, const uint64_t* coset_mont, int threads);
 int jfo_fp_unop(int field_id, int op, const uint64_t* a, uint64_t* out, size_t n);
+int jfo_fp_binop(int field_id, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
 }
 
 using namespace jf_pcs;
@@ -192,6 +193,66 @@ static void run(const uint64_t* g_xy) {
         CHECK(cb.is_ok());
         for (size_t i = 0; i < 131; i++) CHECK(cb.unwrap()[i] == shortc[i]);
         CHECK(Radix2EvaluationDomain<E>::create((size_t)1 << 33).is_err());
+    }
+    // MultilinearKzgPCS::commit / open (pcs/src/multilinear_kzg/mod.rs:123-149, 288-358).  The levels are ranges of the
+    // generated points: the MSM sites see nothing else of the parameter.
+    {
+        using ML = MultilinearKzgPCS<E>;
+        const size_t num_vars = 8;
+        MultilinearProverParam<E> mpp;
+        mpp.num_vars = num_vars;
+        std::vector<size_t> level_at;
+        size_t at = 0;
+        for (size_t i = 0; i <= num_vars; i++) {
+            const size_t sz = (size_t)1 << (num_vars - i);
+            level_at.push_back(at);
+            mpp.powers_of_g.emplace_back(pp.powers_of_g.begin() + at, pp.powers_of_g.begin() + at + sz);
+            at += sz;
+        }
+        auto dpp = ML::load_prover_param_to_gpu(mpp);
+        CHECK(dpp.is_ok());
+        const int fid = E::ID == 0 ? 0 : 2;
+        for (size_t nv : {(size_t)8, (size_t)5}) {
+            DenseMultilinearExtension poly;
+            poly.num_vars = nv;
+            for (size_t i = 0; i < ((size_t)1 << nv); i++) poly.evaluations.push_back(rand_fr());
+            std::vector<Fr> point(nv);
+            for (auto& z : point) z = rand_fr();
+            auto com = ML::commit(*dpp.unwrap(), poly);
+            CHECK(com.is_ok());
+            std::vector<uint64_t> out(PT);
+            jfo_msm(E::ID, &packed[level_at[num_vars - nv] * PT], poly.evaluations[0].data(), poly.evaluations.size(),
+                    out.data(), 8);
+            CHECK(com.unwrap().point == from_packed<E>(out.data()));
+            auto op = ML::open(*dpp.unwrap(), poly, point);
+            CHECK(op.is_ok() && op.unwrap().first.proofs.size() == nv);
+            std::vector<Fr> f = poly.evaluations;
+            const size_t ignored = num_vars - nv + 1;
+            for (size_t i = 0; i < nv; i++) {
+                const size_t half = f.size() / 2;
+                std::vector<Fr> q(half), r(half);
+                for (size_t b = 0; b < half; b++) {
+                    Fr t;
+                    jfo_fp_binop(fid, 1, f[2 * b + 1].data(), f[2 * b].data(), q[b].data(), 1);
+                    jfo_fp_binop(fid, 2, q[b].data(), point[i].data(), t.data(), 1);
+                    jfo_fp_binop(fid, 0, f[2 * b].data(), t.data(), r[b].data(), 1);
+                }
+                jfo_msm(E::ID, &packed[level_at[ignored + i] * PT], q[0].data(), half, out.data(), 8);
+                CHECK(op.unwrap().first.proofs[i] == from_packed<E>(out.data()));
+                f = r;
+            }
+            CHECK(op.unwrap().second == f[0]);
+        }
+        DenseMultilinearExtension big;
+        big.num_vars = num_vars + 1;
+        big.evaluations.assign((size_t)2 << num_vars, rand_fr());
+        auto e1 = ML::commit(*dpp.unwrap(), big);
+        CHECK(e1.is_err() && e1.unwrap_err().msg.find("exceeds param limit") != std::string::npos);
+        DenseMultilinearExtension p3;
+        p3.num_vars = 3;
+        p3.evaluations.assign(8, rand_fr());
+        auto e2 = ML::open(*dpp.unwrap(), p3, std::vector<Fr>(2, rand_fr()));
+        CHECK(e2.is_err() && e2.unwrap_err().msg.find("does not match point len") != std::string::npos);
     }
     std::printf("%s ok\n", E::ID == 0 ? "bn254" : "bls12_381");
 }

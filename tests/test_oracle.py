@@ -140,3 +140,34 @@ def test_intt_reference_known_answers():
         got = C.ntt(cv.curve_id, data, log_n, True, None)
         assert from_mont_arr(cv.fr, got) == coeffs, cite
         assert (C.ntt(cv.curve_id, got, log_n, False, None) == data).all(), cite
+
+
+@pytest.mark.parametrize("cv", [R.BN254, R.BLS12_381], ids=lambda c: c.name)
+def test_mle_oracle_identities(cv):
+    """the multilinear restatement against the scheme's own defining identities with the trapdoor known
+    (pcs/src/multilinear_kzg/srs.rs:337-340 asserts the first of them; verify_internal, mod.rs:368-420, the second in
+    the exponent): commit = [f(t)] g and f(t) - f(z) = sum_i q_i(t_(i+1..)) (t_i - z_i), proofs[i] = [q_i(t_(i+1..))] g"""
+    r = cv.fr.p
+    nv = 4
+    rng = R.SplitMix64(77 + cv.curve_id)
+    t = [rng.field(cv.fr) for _ in range(nv)]
+    z = [rng.field(cv.fr) for _ in range(nv)]
+    evals = [rng.field(cv.fr) for _ in range(1 << nv)]
+    srs = R.mle_srs_for_testing(cv, cv.g, t)
+    assert [len(l) for l in srs] == [16, 8, 4, 2, 1] and srs[nv] == [cv.g]
+    ft = R.mle_evaluate(cv, evals, t)
+    assert R.mle_commit(cv, srs, nv, evals) == R.ec_mul(cv, ft, cv.g)
+    proofs, val = R.mle_open(cv, srs, nv, evals, z)
+    assert val == R.mle_evaluate(cv, evals, z)
+    # exponents of the proofs: q_i over the remaining variables, evaluated at t_(i+1..)
+    f, acc = list(evals), 0
+    for i in range(nv):
+        q = [(f[2 * b + 1] - f[2 * b]) % r for b in range(len(f) // 2)]
+        f = [(f[2 * b] + q[b] * z[i]) % r for b in range(len(f) // 2)]
+        qt = R.mle_evaluate(cv, q, t[i + 1:]) if i + 1 < nv else q[0]
+        assert proofs[i] == R.ec_mul(cv, qt, cv.g)
+        acc = (acc + qt * (t[i] - z[i])) % r
+    assert acc == (ft - val) % r
+    # a polynomial with fewer variables than the parameter: the first levels are skipped
+    sub = evals[:4]
+    assert R.mle_commit(cv, srs, nv, sub) == R.ec_mul(cv, R.mle_evaluate(cv, sub, t[2:]), cv.g)
