@@ -5,6 +5,7 @@
 // Names, argument meaning and error behaviour follow the reference:
 //   PolynomialCommitmentScheme for UnivariateKzgPCS<E>     pcs/src/univariate_kzg/mod.rs:59-211
 //     commit / batch_commit / open / batch_open            :90-125 / :128-140 / :144-180 / :187-211
+//     multi_open_rou_proofs (FK23)                         :328-395
 //   GPUCommittable<E>                                      pcs/src/univariate_kzg/mod.rs:659-965
 //     gpu_commit, gpu_commit_with_loaded_prover_param, gpu_batch_commit,
 //     gpu_batch_commit_with_loaded_prover_param, load_prover_param_to_gpu, load_poly_to_gpu,
@@ -349,6 +350,21 @@ class UnivariateKzgPCS {
             evals.push_back(r.unwrap().second);
         }
         return std::make_pair(std::move(proofs), std::move(evals));
+    }
+
+    // UnivariatePCS::multi_open_rou_proofs (:328-395, FK23): proofs at the first num_points points of `domain`
+    // (2^log_domain elements); multi_open_rou_evals (:397-417) is Radix2EvaluationDomain::fft below
+    static Result<std::vector<UnivariateKzgProof<E>>> multi_open_rou_proofs(DeviceSrs<E>& srs, const Polynomial& poly,
+                                                                            size_t num_points, uint32_t log_domain) {
+        std::vector<uint64_t> xy(num_points * 2 * E::FQ_LIMBS + 1);
+        std::vector<uint8_t> inf(num_points + 1);
+        int32_t rc = jfhip_kzg_multi_open_rou(srs.get(), poly.coeffs.empty() ? nullptr : poly.coeffs[0].data(),
+                                              poly.coeffs.size(), log_domain, num_points, xy.data(), inf.data(), nullptr);
+        if (rc) return last_error(rc);
+        std::vector<UnivariateKzgProof<E>> proofs;
+        for (size_t i = 0; i < num_points; i++)
+            proofs.push_back(UnivariateKzgProof<E>{to_affine(&xy[i * 2 * E::FQ_LIMBS], inf[i])});
+        return proofs;
     }
 
     // ===== the trait's own signatures: commit / batch_commit / open take the HOST prover parameters =====

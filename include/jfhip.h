@@ -178,6 +178,16 @@ int32_t jfhip_g1_sum_partials(int32_t curve_id, const void *d_partials_xyzz, siz
 int32_t jfhip_kzg_open(const jfhip_srs *srs, const uint64_t *coeffs_mont, size_t n, const uint64_t *point_mont,
                        void *out_proof_xy, uint8_t *out_infinity, uint64_t *out_eval_mont, jfhip_stream *stream);
 
+/* Replaces UnivariatePCS::multi_open_rou_proofs (pcs/src/univariate_kzg/mod.rs:328-395, FK23): the opening proofs
+ * of one polynomial at the first num_points points w^j of the domain of 2^log_domain elements, proofs[j] =
+ * commit((f(X) - f(w^j)) / (X - w^j)).  The h-polynomial (compute_h_poly_parallel / compute_h_poly_in_fk23, :572-650) is
+ * a Toeplitz product over group elements, run as group-element DFTs (pcs/src/toeplitz.rs:43-66, pcs/src/poly.rs:
+ * 140-155) on the device, followed by the group DFT over the domain.  coeffs_mont: n Fr coefficients (host).  A
+ * polynomial whose h has more coefficients than the domain is JFHIP_ERR_INVALID with poly.rs:145-150's message.  The
+ * evaluations f(w^j) (multi_open_rou_evals, :397-417) are jfhip_ntt of the coefficients. */
+int32_t jfhip_kzg_multi_open_rou(const jfhip_srs *srs, const uint64_t *coeffs_mont, size_t n, uint32_t log_domain,
+                                 size_t num_points, void *out_proofs_xy, uint8_t *out_infinity, jfhip_stream *stream);
+
 /* ---- Multilinear KZG --------------------------------------------------- */
 
 /* MultilinearKzgPCS::commit / batch_commit (pcs/src/multilinear_kzg/mod.rs:123-174) are

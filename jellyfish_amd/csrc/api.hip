@@ -746,6 +746,63 @@ int32_t jfhip_kzg_open(const jfhip_srs* srs, const uint64_t* coeffs, size_t n, c
     return JFHIP_OK;
 }
 
+// ---- FK23 multi-open at roots of unity ----------------------------------------------
+
+int32_t jfhip_kzg_multi_open_rou(const jfhip_srs* srs, const uint64_t* coeffs, size_t n, uint32_t log_domain,
+                                 size_t num_points, void* out_xy, uint8_t* out_inf, jfhip_stream* stream) {
+    if (!srs || (n && !coeffs) || (num_points && (!out_xy || !out_inf))) {
+        set_error("null argument");
+        return JFHIP_ERR_INVALID;
+    }
+    const uint32_t adicity = srs->curve == JFHIP_BN254 ? 28u : 32u;
+    if (log_domain > adicity || log_domain > 26) {
+        set_error("multi_open_rou: domain of 2^%u points unsupported", log_domain);
+        return JFHIP_ERR_INVALID;
+    }
+    const size_t dom = (size_t)1 << log_domain;
+    if (num_points > dom) {
+        set_error("multi_open_rou: %zu points exceed the domain size %zu", num_points, dom);
+        return JFHIP_ERR_INVALID;
+    }
+    // the h-polynomial has n - 1 coefficients: it must fit the domain (batch_evaluate_rou, pcs/src/poly.rs:143-150)
+    if (n > 1 && n - 1 > dom) {
+        set_error("Polynomial with %zu num_of_coeffs can't be evaluated on a smaller domain with size %zu", n - 1, dom);
+        return JFHIP_ERR_INVALID;
+    }
+    if (num_points == 0) return JFHIP_OK;
+    const size_t pt = 2 * (size_t)fq_bytes(srs->curve);
+    if (n <= 1) {   // constant polynomial: every quotient (f - f(z)) / (X - z) is zero
+        memset(out_xy, 0, num_points * pt);
+        memset(out_inf, 1, num_points);
+        return JFHIP_OK;
+    }
+    JF_TRY(check_msm_range(srs, 0, n - 1));
+    uint32_t log_M = 1;
+    while (((size_t)1 << log_M) < 2 * (n - 1)) log_M++;
+    if (log_M > adicity || log_M > 27) {
+        set_error("multi_open_rou: polynomial too long");
+        return JFHIP_ERR_INVALID;
+    }
+    JF_STREAM(st, stream);
+    std::lock_guard<std::mutex> lk(st->mu);
+    const size_t rec = (pt + 4 + 15) & ~(size_t)15;
+    JF_TRY(st->poly_a.ensure(n * 32));
+    JF_TRY(st->ntt_io.ensure(num_points * rec));
+    JF_HIP(hipMemcpyAsync(st->poly_a.p, coeffs, n * 32, hipMemcpyHostToDevice, st->s));
+    JF_TRY(multi_open_rou_device(srs, st->poly_a.as<uint32_t>(), n, log_domain, num_points, st->ntt_io.as<uint32_t>(), rec,
+                                 log_M, st));
+    std::vector<uint8_t> host(num_points * rec);
+    JF_HIP(hipMemcpyAsync(host.data(), st->ntt_io.p, num_points * rec, hipMemcpyDeviceToHost, st->s));
+    JF_HIP(hipStreamSynchronize(st->s));
+    for (size_t i = 0; i < num_points; i++) {
+        memcpy((uint8_t*)out_xy + i * pt, host.data() + i * rec, pt);
+        uint32_t inf;
+        memcpy(&inf, host.data() + i * rec + pt, 4);
+        out_inf[i] = inf ? 1 : 0;
+    }
+    return JFHIP_OK;
+}
+
 // ---- multilinear KZG (the MSM sites of pcs/src/multilinear_kzg/mod.rs) --------------
 
 int32_t jfhip_mle_fold_device(int32_t curve_id, const void* d_f, size_t half, const uint64_t* point, void* d_q, void* d_r,

@@ -36,7 +36,7 @@ SYMBOLS = [
     "jfhip_srs_load_serialized", "jfhip_msm_small",
     "jfhip_srs_gen_for_testing", "jfhip_srs_free", "jfhip_srs_len", "jfhip_srs_window_bits", "jfhip_srs_read",
     "jfhip_msm", "jfhip_msm_batch", "jfhip_msm_batch_device", "jfhip_msm_device", "jfhip_msm_partial_device", "jfhip_g1_sum_partials",
-    "jfhip_kzg_open", "jfhip_mle_open", "jfhip_mle_fold_device", "jfhip_ntt", "jfhip_ntt_device", "jfhip_plonk_quotient_turbo_device", "jfhip_plonk_quotient_ultra_device", "jfhip_plonk_quotient_coset_device", "jfhip_plonk_quotient_masked_device", "jfhip_plonk_perm_product_device", "jfhip_plonk_lookup_product_device", "jfhip_plonk_lookup_merge_device", "jfhip_witness_gather_device", "jfhip_poly_divide_linear_device", "jfhip_poly_divide_linear_noalloc_device",
+    "jfhip_kzg_open", "jfhip_kzg_multi_open_rou", "jfhip_mle_open", "jfhip_mle_fold_device", "jfhip_ntt", "jfhip_ntt_device", "jfhip_plonk_quotient_turbo_device", "jfhip_plonk_quotient_ultra_device", "jfhip_plonk_quotient_coset_device", "jfhip_plonk_quotient_masked_device", "jfhip_plonk_perm_product_device", "jfhip_plonk_lookup_product_device", "jfhip_plonk_lookup_merge_device", "jfhip_witness_gather_device", "jfhip_poly_divide_linear_device", "jfhip_poly_divide_linear_noalloc_device",
     "jfhip_poly_lincomb_device", "jfhip_poly_eval_batch_device", "jfhip_field_op", "jfhip_g1_op", "jfhip_probe",
     "jfhip_set_profiling", "jfhip_last_phase_ms", "jfhip_phase_name", "jfhip_keccak_f1600",
 ]
@@ -280,6 +280,18 @@ def kzg_open(srs: Srs, coeffs_mont, point_mont, stream: Stream | None = None):
     _check(load_library().jfhip_kzg_open(srs.h, _p(c) if n else None, ctypes.c_size_t(n), _p(z), _p(out),
                                          ctypes.byref(inf), _p(ev), _sh(stream)))
     return out, bool(inf.value), ev
+
+
+def kzg_multi_open_rou(srs: Srs, coeffs_mont, log_domain: int, num_points: int, stream: Stream | None = None):
+    """UnivariatePCS::multi_open_rou_proofs -> (proofs (num_points, 2 * fq limbs), identity flags)"""
+    c = _u64(coeffs_mont)
+    n = c.size // 4
+    out = np.zeros((num_points, 2 * FQ_LIMBS64[srs.curve]), dtype=np.uint64)
+    inf = np.zeros(num_points, dtype=np.uint8)
+    _check(load_library().jfhip_kzg_multi_open_rou(srs.h, _p(c) if n else None, ctypes.c_size_t(n), log_domain,
+                                                   ctypes.c_size_t(num_points), _p(out) if num_points else None,
+                                                   _p(inf) if num_points else None, _sh(stream)))
+    return out, inf.astype(bool)
 
 
 def mle_open(levels, evals_mont, point_mont, stream: Stream | None = None):

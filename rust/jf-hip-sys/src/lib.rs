@@ -153,6 +153,16 @@ extern "C" {
         out_eval_mont: *mut u64,
         stream: *mut jfhip_stream,
     ) -> i32;
+    pub fn jfhip_kzg_multi_open_rou(
+        srs: *const jfhip_srs,
+        coeffs_mont: *const u64,
+        n: usize,
+        log_domain: u32,
+        num_points: usize,
+        out_proofs_xy: *mut c_void,
+        out_infinity: *mut u8,
+        stream: *mut jfhip_stream,
+    ) -> i32;
     pub fn jfhip_mle_open(
         levels: *const *const jfhip_srs,
         nv: usize,

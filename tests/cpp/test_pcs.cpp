@@ -194,6 +194,26 @@ static void run(const uint64_t* g_xy) {
         for (size_t i = 0; i < 131; i++) CHECK(cb.unwrap()[i] == shortc[i]);
         CHECK(Radix2EvaluationDomain<E>::create((size_t)1 << 33).is_err());
     }
+    // multi_open_rou_proofs == per-point open (the reference's own assertion, mod.rs:1237-1301)
+    {
+        DensePolynomial p = rand_poly(37);
+        const uint32_t log_domain = 6;
+        auto proofs = PCS::multi_open_rou_proofs(srs.unwrap(), p, 40, log_domain);
+        CHECK(proofs.is_ok() && proofs.unwrap().size() == 40);
+        auto dom = Radix2EvaluationDomain<E>::create((size_t)1 << log_domain);
+        std::vector<Fr> unit(2, Fr{0, 0, 0, 0});
+        const uint64_t one_bn[4] = {0xac96341c4ffffffbull, 0x36fc76959f60cd29ull, 0x666ea36f7879462eull, 0x0e0a77c19a07df2full};
+        const uint64_t one_bls[4] = {0x00000001fffffffeull, 0x5884b7fa00034802ull, 0x998c4fefecbc4ff5ull, 0x1824b159acc5056full};
+        std::memcpy(unit[1].data(), E::ID == 0 ? one_bn : one_bls, 32);   // the polynomial X: its evaluations are w^j
+        auto ws = dom.unwrap().fft(unit);
+        CHECK(ws.is_ok());
+        for (size_t j : {(size_t)0, (size_t)1, (size_t)17, (size_t)39}) {
+            auto op = PCS::open(srs.unwrap(), p, ws.unwrap()[j]);
+            CHECK(op.is_ok() && op.unwrap().first.proof == proofs.unwrap()[j].proof);
+        }
+        auto bad = PCS::multi_open_rou_proofs(srs.unwrap(), rand_poly(100), 4, 5);
+        CHECK(bad.is_err() && bad.unwrap_err().msg.find("smaller domain") != std::string::npos);
+    }
     // MultilinearKzgPCS::commit / open (pcs/src/multilinear_kzg/mod.rs:123-149, 288-358).  The levels are ranges of the
     // generated points: the MSM sites see nothing else of the parameter.
     {
