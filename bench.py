@@ -522,6 +522,26 @@ def main():
                          "unit": "GB/s", "frac": round(alg_bytes / (acc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                          "measured_copy_GBs": round(copy_bw / 1e9, 1)},
         }
+        # VALU issue evidence from the rocprofv3 --pmc passes of the same workload (scripts/pmc_valu.sh, committed summary):
+        # wave-instructions issued per shader cycle over the chip (1024 SIMDs; a wave64 v_mad_u64_u32 occupies its SIMD for
+        # 4 cycles, 32-bit adds / shifts / moves for 2)
+        try:
+            pv = json.load(open(os.path.join(ROOT, "profiles", "pmc_valu_latest.json")))["kernels"]
+            kk = [k for k in pv if "k_msm_accumulate" in k and "Bn254" in k]
+            if kk:
+                d = pv[kk[0]]
+                cyc = d["GRBM_GUI_ACTIVE"] / 8.0
+                out["roofline"]["valu_pmc"] = {
+                    "kernel": kk[0], "source": "profiles/pmc_valu_latest.json (rocprofv3 --pmc, 2^24 points)",
+                    "SQ_INSTS_VALU_per_launch": d["SQ_INSTS_VALU"], "shader_cycles_per_launch": round(cyc),
+                    "valu_wave_insts_per_cycle_chip": round(d["SQ_INSTS_VALU"] / cyc, 1),
+                    "valu_insts_per_mixed_add": round(d["SQ_INSTS_VALU"] * 64.0 / (windows * float(1 << 24)), 1),
+                    "int64_class_insts_per_launch": d.get("SQ_INSTS_VALU_INT64"),
+                    "mad_issue_cycles_frac": round(d.get("SQ_INSTS_VALU_INT64", 0.0) * 4.0 / (cyc * 1024.0), 3),
+                    "wait_inst_any_frac_of_wave_cycles": d.get("frac_of_wave_cycles:SQ_WAIT_INST_ANY"),
+                }
+        except Exception:
+            pass
         # second wall of this kernel: every mixed addition gathers one random 64-byte table point.  jfhip_probe(4, GiB)
         # measures the device's random 64-byte gather rate over a table of the same size, nothing else running.
         table_gib = max(1, int(round(windows * n * 64 / 2**30)))
