@@ -174,7 +174,7 @@ def real_prove_section(L, torch, dist, world, log_g=20):
     # second mode: the proving key keeps its 18 selector / sigma coset evaluations (this rank's slice) in HBM
     rank = dist.get_rank() if world > 1 else 0
     pk.keep_coset_evals(rank=rank, world=world)
-    kept_bytes = pk.coset_evals.numel() * 8
+    kept_bytes = pk.coset_evals_bytes()
     JP.PlonkKzgSnark.prove(rng, cs, pk, witness_mont=wit, sharded=world > 1)
     ts_kept = timed()
     m = pk.quot_domain_size()

@@ -318,6 +318,15 @@ int32_t jfhip_plonk_lookup_merge_device(int32_t curve_id, uint32_t log_n, const 
                                         const void *d_table_vals, const uint64_t *tau_mont, void *d_merged_table,
                                         void *d_merged_lookup, jfhip_stream *stream);
 
+/* Replaces the HashMap merge of compute_lookup_sorted_vec_polynomials (relation/src/constraint_system.rs:1597-1620)
+ * on DEVICE data: d_sorted = every row of d_table (n_table field elements of 32 bytes, the merged lookup table) in
+ * table order, each followed by as many copies as d_lookups (n_lookups rows, the first n - 1 merged lookup-wire values)
+ * holds of it, counted at the value's FIRST occurrence in the table; n_table + n_lookups rows.  A lookup value that the
+ * table does not hold is JFHIP_ERR_INVALID with the reference's message ("The sorted vector has wrong length, some
+ * lookup variables might be outside the table", :1613-1615).  Synchronous: the status is read back. */
+int32_t jfhip_plonk_lookup_sorted_device(const void *d_table, size_t n_table, const void *d_lookups, size_t n_lookups,
+                                         void *d_sorted, jfhip_stream *stream);
+
 /* ---- device-resident polynomial glue (next row) -------------------------- */
 
 /* Replaces the witness-polynomial division of open() / compute_batched_witness_polynomial_commitment

@@ -1053,6 +1053,18 @@ int32_t jfhip_plonk_lookup_merge_device(int32_t curve_id, uint32_t log_n, const 
                                      (uint32_t*)d_merged_table, (uint32_t*)d_merged_lookup, st);
 }
 
+int32_t jfhip_plonk_lookup_sorted_device(const void* d_table, size_t n_table, const void* d_lookups, size_t n_lookups,
+                                         void* d_sorted, jfhip_stream* stream) {
+    if (!d_table || !d_sorted || (n_lookups && !d_lookups)) {
+        set_error("null argument");
+        return JFHIP_ERR_INVALID;
+    }
+    JF_STREAM(st, stream);
+    std::lock_guard<std::mutex> lk(st->mu);
+    return plonk_lookup_sorted_device((const uint32_t*)d_table, n_table, (const uint32_t*)d_lookups, n_lookups,
+                                      (uint32_t*)d_sorted, st);
+}
+
 int32_t jfhip_poly_divide_linear_device(int32_t curve_id, const void* d_coeffs, size_t n, const uint64_t* point,
                                         void* d_out, jfhip_stream* stream) {
     JF_TRY(check_curve(curve_id));

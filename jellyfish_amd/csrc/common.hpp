@@ -224,6 +224,8 @@ int32_t witness_gather_device(const uint32_t* d_witness, size_t num_vars, const 
                               uint32_t* d_out, jfhip_stream* st);
 int32_t multi_open_rou_device(const jfhip_srs* srs, const uint32_t* d_coeffs, size_t ncoeffs, uint32_t log_dom,
                               size_t num_points, uint32_t* d_out, size_t rec_bytes, uint32_t log_M, jfhip_stream* st);
+int32_t plonk_lookup_sorted_device(const uint32_t* d_table, size_t n, const uint32_t* d_lookups, size_t n_lookups,
+                                   uint32_t* d_sorted, jfhip_stream* st);
 int32_t mle_fold_device(int32_t curve, const uint32_t* d_f, size_t half, const uint32_t* d_point, uint32_t* d_q,
                         uint32_t* d_r, jfhip_stream* st);
 int32_t poly_lincomb_device(int32_t curve, const uint32_t* const* d_polys, const size_t* lens, size_t count,

@@ -1567,7 +1567,9 @@ static int32_t msm_partial_t(const jfhip_srs* srs, size_t offset, const uint32_t
     JF_TRY(st->buckets.ensure((size_t)B * XZ * 4));
     // fold: g buckets per lane, then a sum tree (the fold output reuses partA after the fix-up)
     // latency-bound for small bucket counts (few lanes, deep chains): short chains there
+    static const int env_g = getenv("JFHIP_MSM_FOLD_G") ? atoi(getenv("JFHIP_MSM_FOLD_G")) : 0;
     uint32_t g = (B <= (1u << 17)) ? 4 : 16;
+    if (env_g > 0) g = (uint32_t)env_g;
     const uint32_t Tf = (B + g - 1) / g;
     JF_TRY(st->partA.ensure((T > Tf ? T : Tf) * XZ * 4));
     JF_TRY(st->partB.ensure(T * XZ * 4));

@@ -36,7 +36,7 @@ SYMBOLS = [
     "jfhip_srs_load_serialized", "jfhip_msm_small",
     "jfhip_srs_gen_for_testing", "jfhip_srs_free", "jfhip_srs_len", "jfhip_srs_window_bits", "jfhip_srs_read",
     "jfhip_msm", "jfhip_msm_batch", "jfhip_msm_batch_device", "jfhip_msm_device", "jfhip_msm_partial_device", "jfhip_g1_sum_partials",
-    "jfhip_kzg_open", "jfhip_kzg_multi_open_rou", "jfhip_mle_open", "jfhip_mle_fold_device", "jfhip_ntt", "jfhip_ntt_device", "jfhip_plonk_quotient_turbo_device", "jfhip_plonk_quotient_ultra_device", "jfhip_plonk_quotient_coset_device", "jfhip_plonk_quotient_masked_device", "jfhip_plonk_perm_product_device", "jfhip_plonk_lookup_product_device", "jfhip_plonk_lookup_merge_device", "jfhip_witness_gather_device", "jfhip_poly_divide_linear_device", "jfhip_poly_divide_linear_noalloc_device",
+    "jfhip_kzg_open", "jfhip_kzg_multi_open_rou", "jfhip_mle_open", "jfhip_mle_fold_device", "jfhip_ntt", "jfhip_ntt_device", "jfhip_plonk_quotient_turbo_device", "jfhip_plonk_quotient_ultra_device", "jfhip_plonk_quotient_coset_device", "jfhip_plonk_quotient_masked_device", "jfhip_plonk_perm_product_device", "jfhip_plonk_lookup_product_device", "jfhip_plonk_lookup_merge_device", "jfhip_plonk_lookup_sorted_device", "jfhip_witness_gather_device", "jfhip_poly_divide_linear_device", "jfhip_poly_divide_linear_noalloc_device",
     "jfhip_poly_lincomb_device", "jfhip_poly_eval_batch_device", "jfhip_field_op", "jfhip_g1_op", "jfhip_probe",
     "jfhip_set_profiling", "jfhip_last_phase_ms", "jfhip_phase_name", "jfhip_keccak_f1600",
 ]
@@ -280,6 +280,12 @@ def kzg_open(srs: Srs, coeffs_mont, point_mont, stream: Stream | None = None):
     _check(load_library().jfhip_kzg_open(srs.h, _p(c) if n else None, ctypes.c_size_t(n), _p(z), _p(out),
                                          ctypes.byref(inf), _p(ev), _sh(stream)))
     return out, bool(inf.value), ev
+
+
+def plonk_lookup_sorted_device(d_table: int, n_table: int, d_lookups: int, n_lookups: int, d_sorted: int,
+                               stream: Stream | None = None):
+    _check(load_library().jfhip_plonk_lookup_sorted_device(_vp(d_table), ctypes.c_size_t(n_table), _vp(d_lookups),
+                                                           ctypes.c_size_t(n_lookups), _vp(d_sorted), _sh(stream)))
 
 
 def kzg_multi_open_rou(srs: Srs, coeffs_mont, log_domain: int, num_points: int, stream: Stream | None = None):

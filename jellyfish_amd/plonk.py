@@ -394,12 +394,21 @@ class ProvingKey:
     # proving key only, and 288 GB of HBM holds them (18 x 256 MiB at n = 2^20).  Same values, so the same proof bytes.
     coset_evals: torch.Tensor = field(repr=False, default=None)
     coset_slice: tuple = (0, 1)   # (rank, world) the resident evaluations were computed for
+    # the same, one tensor per slice (g, G) of quotient_slices(): what the one-GPU prover evaluates the quotient on
+    coset_evals_slices: dict = field(repr=False, default=None)
     # selector polynomials that are identically zero for this circuit (a gate kind it never uses): their coset
     # evaluations are zero, so prove() fills those rows instead of transforming them (same values, same proof bytes)
     selector_is_zero: tuple = ()
 
     def domain_size(self) -> int:
         return self.vk.domain_size
+
+    def coset_evals_bytes(self) -> int:
+        """HBM held by keep_coset_evals()"""
+        ts = list(self.coset_evals_slices.values()) if self.coset_evals_slices else []
+        if self.coset_evals is not None:
+            ts.append(self.coset_evals)
+        return sum(t.numel() * 8 for t in ts)
 
     def quot_domain_size(self) -> int:
         n, W = self.vk.domain_size, self.sigmas.shape[0]
@@ -410,26 +419,42 @@ class ProvingKey:
 
     def keep_coset_evals(self, stream=None, rank: int = 0, world: int = 1) -> "ProvingKey":
         """evaluate selectors, sigmas (and the Plookup tables) on the quotient coset once and keep them resident (see
-        coset_evals).  world > 1: only rank's slice of the coset (prove(sharded=True) with coset sharding)"""
+        coset_evals).  world > 1: only rank's slice of the coset (prove(sharded=True) with coset sharding); world == 1:
+        the slices of quotient_slices(), which is what the one-GPU prover evaluates the quotient on"""
         cp = H.CURVES[self.curve]
         n, m = self.vk.domain_size, self.quot_domain_size()
         if not coset_sharding_applies(n, m, world):
             rank, world = 0, 1
-        ml = m // world
         nsel, W = self.selectors.shape[0], self.sigmas.shape[0]
         ntab = 4 if self.supports_lookup else 0
         st = _stream(stream)
-        with _torch_on(st):
-            ev = torch.empty(nsel + W + ntab, ml * 4, dtype=torch.int64, device="cuda")
-            ev[:nsel, :n * 4].copy_(self.selectors)
-            ev[nsel:nsel + W, :n * 4].copy_(self.sigmas)
-            if ntab:
-                ev[nsel + W:, :n * 4].copy_(self.plookup_polys)
-            off = H.fr_to_mont(cp, [slice_offset(cp, m, rank)])[0]
-            L.ntt_device(self.curve, ev.data_ptr(), ml.bit_length() - 1, nsel + W + ntab, inverse=False, coset_mont=off,
-                         in_len=n, stream=st)
-        self.coset_evals = ev
-        self.coset_slice = (rank, world)
+
+        def evals_on(g, G):
+            ml = m // G
+            with _torch_on(st):
+                ev = torch.zeros(nsel + W + ntab, ml * 4, dtype=torch.int64, device="cuda")
+                rows = [self.selectors, self.sigmas] + ([self.plookup_polys] if ntab else [])
+                at = 0
+                for polys in rows:
+                    k = polys.shape[0]
+                    if ml >= n:
+                        ev[at:at + k, :n * 4].copy_(polys)
+                    else:                 # never: selectors have n coefficients and the smallest slice n points
+                        raise PlonkError("slice smaller than the domain")
+                    at += k
+                off = H.fr_to_mont(cp, [slice_offset(cp, m, g)])[0]
+                L.ntt_device(self.curve, ev.data_ptr(), ml.bit_length() - 1, nsel + W + ntab, inverse=False,
+                             coset_mont=off, in_len=n, stream=st)
+            return ev
+
+        slices = quotient_slices(n, m, W * (n + 1) + 3) if (world == 1 and QUOTIENT_SLICES) else [(rank, world)]
+        if len(slices) > 1:
+            self.coset_evals, self.coset_slice = None, (0, 1)
+            self.coset_evals_slices = {sl: evals_on(*sl) for sl in slices}
+        else:
+            self.coset_evals_slices = None
+            self.coset_evals = evals_on(rank, world)
+            self.coset_slice = (rank, world)
         return self
 
 
@@ -876,44 +901,21 @@ def unslice_quotient(cp, curve: int, parts, slices, m: int, stream) -> torch.Ten
     return out
 
 
-def _row_ids(rows: torch.Tensor) -> torch.Tensor:
-    """equal rows (4 x int64) -> equal ids: one 64-bit radix sort of a mixing key instead of a lexicographic sort of the
-    256-bit rows (torch.unique(dim=0): 80 ms for 2^23 rows).  Exact: rows are compared in full between sorted neighbours,
-    and two different rows sharing a key (a 2^-64 event per pair) send the call to the lexicographic sort."""
-    key = rows[:, 0] * -7046029254386353131 + rows[:, 1] * -4417276706812531889 \
-        + rows[:, 2] * 1609587929392839161 + rows[:, 3] * -8796714831421723037
-    key = key ^ (key >> 29)
-    ks, order = torch.sort(key)
-    rs = rows[order]
-    diff_row = (rs[1:] != rs[:-1]).any(dim=1)
-    if bool(((ks[1:] == ks[:-1]) & diff_row).any().item()):
-        return torch.unique(rows, dim=0, return_inverse=True)[1]
-    ids_sorted = torch.cat([torch.zeros(1, dtype=torch.int64, device=rows.device), torch.cumsum(diff_row.to(torch.int64), 0)])
-    inv = torch.empty_like(ids_sorted)
-    inv[order] = ids_sorted
-    return inv
-
-
-def _sorted_lookup_vector(table: torch.Tensor, lookups: torch.Tensor) -> torch.Tensor:
+def _sorted_lookup_vector(table: torch.Tensor, lookups: torch.Tensor, stream=None) -> torch.Tensor:
     """compute_lookup_sorted_vec_polynomials (relation/src/constraint_system.rs:1597-1620) before its two iffts, on
     device rows of 4 x int64 (one field element each; equal elements have equal Montgomery limbs): every table element,
     in table order, followed by as many copies as it is looked up -- counted at its FIRST occurrence in the table, as
-    the reference's HashMap entry is removed once used.  table: (n, 4), lookups: (n - 1, 4) -> (2n - 1, 4)."""
-    n = table.shape[0]
-    both = torch.cat([table, lookups])
-    inv = _row_ids(both)
-    tid, lid = inv[:n], inv[n:]
-    nid = int(inv.max().item()) + 1
-    counts = torch.bincount(lid, minlength=nid)
-    pos = torch.arange(n, device=table.device)
-    first = torch.full((nid,), n, dtype=torch.int64, device=table.device).scatter_reduce(0, tid, pos, "amin")
-    in_table = first < n
-    if bool((counts[~in_table] != 0).any().item()):
-        raise PlonkError("The sorted vector has wrong length, some lookup variables might be outside the table")
-    mult = 1 + torch.where(first[tid] == pos, counts[tid], torch.zeros_like(tid))
-    out = torch.repeat_interleave(table, mult, dim=0)
-    if out.shape[0] != 2 * n - 1:
-        raise PlonkError("The sorted vector has wrong length, some lookup variables might be outside the table")
+    the reference's HashMap entry is removed once used.  table: (n, 4), lookups: (n - 1, 4) -> (2n - 1, 4).
+    jfhip_plonk_lookup_sorted_device: a hash table of first positions, wave-aggregated counts, a scan, an expansion."""
+    n, k = table.shape[0], lookups.shape[0]
+    table, lookups = table.contiguous(), lookups.contiguous()
+    out = torch.empty(n + k, 4, dtype=torch.int64, device=table.device)
+    try:
+        L.plonk_lookup_sorted_device(table.data_ptr(), n, lookups.data_ptr(), k, out.data_ptr(), stream=stream)
+    except L.JfHipError as e:
+        if "sorted vector has wrong length" in str(e):
+            raise PlonkError("The sorted vector has wrong length, some lookup variables might be outside the table") from e
+        raise
     return out
 
 
@@ -1279,7 +1281,7 @@ class PlonkKzgSnark:
             L.plonk_lookup_merge_device(c, log_n, wire_vals_v[i].data_ptr(), pk.plookup_table_vals.data_ptr(),
                                         mont([tau])[0], merged[0].data_ptr(), merged[1].data_ptr(), stream=st)
             # only the first n - 1 rows look up; the sorted concatenation has 2n - 1 entries
-            srt = _sorted_lookup_vector(merged[0].view(n, 4), merged[1].view(n, 4)[:n - 1]).reshape(-1)
+            srt = _sorted_lookup_vector(merged[0].view(n, 4), merged[1].view(n, 4)[:n - 1], st).reshape(-1)
             h_polys = torch.zeros(2, l4, dtype=torch.int64, device="cuda")
             h_polys[0, :n4].copy_(srt[:n4])
             h_polys[1, :n4].copy_(srt[n4 - 4:])
@@ -1374,10 +1376,16 @@ class PlonkKzgSnark:
                 pk, vk, wire_polys, perm_poly = prove_keys[i], vks[i], wire_polys_v[i], perm_poly_v[i]
                 NSEL = pk.selectors.shape[0]
                 nlk = 7 if lookup[i] else 0
-                if pk.coset_evals is not None:
-                    # selector / sigma (/ table) coset evaluations are resident with the proving key
+                fixed = None
+                if pk.coset_evals_slices is not None and (g, G) in pk.coset_evals_slices:
+                    fixed = pk.coset_evals_slices[(g, G)]
+                elif pk.coset_evals is not None:
                     fixed = pk.coset_evals
-                    if fixed.shape != (NSEL + W + (4 if lookup[i] else 0), ml * 4) or pk.coset_slice != (g, G):
+                    if pk.coset_slice != (g, G):
+                        raise PlonkError("proving key coset evaluations were kept for another slice of the quotient coset")
+                if fixed is not None:
+                    # selector / sigma (/ table) coset evaluations are resident with the proving key
+                    if fixed.shape != (NSEL + W + (4 if lookup[i] else 0), ml * 4):
                         raise PlonkError("proving key coset evaluations were kept for another slice of the quotient coset")
                     npolys, o_w = W + 2 + nlk, 0
                     sel_ptr, sig_ptr = fixed[0].data_ptr(), fixed[NSEL].data_ptr()
@@ -1386,7 +1394,7 @@ class PlonkKzgSnark:
                 o_z, o_pi, o_lk = o_w + W, o_w + W + 1, o_w + W + 2
                 cs = torch.empty(npolys, ml * 4, dtype=torch.int64, device="cuda")
                 cs[:, n4:lc4].zero_()
-                if pk.coset_evals is None:
+                if fixed is None:
                     cs[:NSEL, :n4].copy_(pk.selectors)
                     cs[NSEL:o_w, :n4].copy_(pk.sigmas)
                     sel_ptr, sig_ptr = cs[0].data_ptr(), cs[NSEL].data_ptr()
@@ -1397,7 +1405,7 @@ class PlonkKzgSnark:
                 online_rows = list(range(o_w, o_z + 1))
                 if lookup[i]:
                     # the quotient kernel's Plookup rows: range_table, key_table, table_dom_sep, q_dom_sep, h_1, h_2, prod_lookup
-                    if pk.coset_evals is None:
+                    if fixed is None:
                         cs[o_lk:o_lk + 4, :n4].copy_(pk.plookup_polys)
                     cs[o_lk + 4:o_lk + 6, :lc4].copy_(h_polys_v[i][:, :lc4])
                     cs[o_lk + 6, :lc4].copy_(pl_poly_v[i][:lc4])
@@ -1417,13 +1425,13 @@ class PlonkKzgSnark:
                 zmask = sum(1 << j for j, z in enumerate(pk.selector_is_zero) if z) if SKIP_ZERO_POLYS else 0
                 pi_zero = SKIP_ZERO_POLYS and not pub_inputs[i]
                 zero_rows = [o_pi] if pi_zero else []
-                if pk.coset_evals is None:
+                if fixed is None:
                     zero_rows += [j for j in range(NSEL) if (zmask >> j) & 1]
                 elif lookup[i]:
                     zero_rows += list(range(o_lk, o_lk + 4))          # resident: copied below, not transformed
                 _coset_ntt_rows(c, cs, zero_rows, log_ml, off, lc4 // 4, st)
-                if pk.coset_evals is not None and lookup[i]:
-                    cs[o_lk:o_lk + 4].copy_(pk.coset_evals[NSEL + W:])
+                if fixed is not None and lookup[i]:
+                    cs[o_lk:o_lk + 4].copy_(fixed[NSEL + W:])
                 tick("r3_coset_ntts")
                 chal = mont([alpha, beta, gamma] + ([tau] if lookup[i] else []) + [alpha_bases[i]])
                 # G == 1: the slice is the whole quotient coset (offset Fr::GENERATOR, log_ml = log_m)

@@ -295,6 +295,14 @@ extern "C" {
         d_out: *mut c_void,
         stream: *mut jfhip_stream,
     ) -> i32;
+    pub fn jfhip_plonk_lookup_sorted_device(
+        d_table: *const c_void,
+        n_table: usize,
+        d_lookups: *const c_void,
+        n_lookups: usize,
+        d_sorted: *mut c_void,
+        stream: *mut jfhip_stream,
+    ) -> i32;
     pub fn jfhip_plonk_lookup_merge_device(
         curve_id: i32,
         log_n: u32,

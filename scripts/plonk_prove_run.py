@@ -33,7 +33,7 @@ rng = H.test_rng()
 JP.PlonkKzgSnark.prove(rng, cs, pk, witness_mont=wit)
 if os.environ.get("JF_PK_RESIDENT"):
     pk.keep_coset_evals()
-    print("proving key keeps selector / sigma coset evaluations: %.2f GiB" % (pk.coset_evals.numel() * 8 / 2**30))
+    print("proving key keeps selector / sigma coset evaluations: %.2f GiB" % (pk.coset_evals_bytes() / 2**30))
 for _ in range(runs):
     torch.cuda.synchronize()
     t0 = time.perf_counter()

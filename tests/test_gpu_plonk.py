@@ -54,9 +54,20 @@ def test_prove_matches_oracle_and_verifies(hip, cv, size):
     assert proof.as_dict() == oproof
     assert proof.serialize_compressed() == P.ser_proof(cv, oproof)
     # selector / sigma coset evaluations resident with the proving key: 7 transforms instead of 25, same bytes
+    # (per slice of the quotient coset where the prover evaluates on slices, on the whole coset otherwise)
     pk.keep_coset_evals()
+    assert (pk.coset_evals_slices is not None) == (n >= 16)
     assert JP.PlonkKzgSnark.prove(JP.H.test_rng(), cs, pk).serialize_compressed() == P.ser_proof(cv, oproof)
-    pk.coset_evals = None
+    # the reference's own shape: all 8 n points of the coset, with and without resident evaluations
+    JP.QUOTIENT_SLICES = False
+    try:
+        pk.keep_coset_evals()
+        assert pk.coset_evals is not None and pk.coset_evals_slices is None
+        assert JP.PlonkKzgSnark.prove(JP.H.test_rng(), cs, pk).serialize_compressed() == P.ser_proof(cv, oproof)
+        pk.coset_evals = None
+        assert JP.PlonkKzgSnark.prove(JP.H.test_rng(), cs, pk).serialize_compressed() == P.ser_proof(cv, oproof)
+    finally:
+        JP.QUOTIENT_SLICES = True
     pub = cs.public_input()
     assert P.verify(cv, vk.as_dict(), pub, proof.as_dict(), trapdoor_beta=beta)
     # a second proof continues the RNG stream: different blinding, still valid; extra transcript message is bound

@@ -182,3 +182,47 @@ def test_ultra_bench_circuit_proof_verifies(hip, log_gates):
     q = 48
     assert len(proof.serialize_compressed()) == (8 + 6 * q) + q + (8 + 6 * q) + 2 * q + (8 + 6 * 32) + (8 + 5 * 32) + 32 \
         + 1 + (8 + 2 * q) + q + 15 * 32
+
+
+def _sorted_ref(table, lookups):
+    """the reference's HashMap merge (constraint_system.rs:1597-1620) on integers"""
+    cnt = {}
+    for x in lookups:
+        cnt[x] = cnt.get(x, 0) + 1
+    out = []
+    for x in table:
+        out += [x] * (1 + cnt.pop(x, 0))
+    return out if not cnt else None
+
+
+@pytest.mark.parametrize("shape", ["random", "padded", "alternating", "one_value"])
+def test_lookup_sorted_device(hip, shape):
+    """jfhip_plonk_lookup_sorted_device: duplicates in the table (counted at the first occurrence), long runs, millions of
+    equal lookups, a lookup outside the table"""
+    import torch
+
+    rng = np.random.default_rng(5)
+    n = 5000 if shape == "random" else 1 << 16
+    if shape == "random":
+        vals = rng.integers(1, 300, size=n)                       # many repeated, non-adjacent values
+        lk = rng.choice(vals, size=n - 1)
+    elif shape == "padded":
+        vals = np.concatenate([np.arange(1, 257), np.zeros(n - 256, dtype=np.int64)])    # a range table and its padding
+        lk = np.concatenate([rng.integers(0, 257, size=n // 2), np.zeros(n - 1 - n // 2, dtype=np.int64)])
+    elif shape == "alternating":
+        vals = np.tile(np.array([7, 9]), n // 2)
+        lk = np.tile(np.array([9, 7, 7]), n)[:n - 1]
+    else:
+        vals = np.arange(n)
+        lk = np.full(n - 1, 12345)
+    rows = lambda v: torch.from_numpy(np.stack([v * 3 + 1, v ^ 0x55, v * v, v + 2], axis=1).astype(np.int64)).cuda()
+    d_t, d_l = rows(vals), rows(lk)
+    out = torch.zeros(2 * n - 1, 4, dtype=torch.int64, device="cuda")
+    hip.plonk_lookup_sorted_device(d_t.data_ptr(), n, d_l.data_ptr(), n - 1, out.data_ptr())
+    want = _sorted_ref(list(vals), list(lk))
+    assert torch.equal(out.cpu(), rows(np.array(want)).cpu())
+    # one lookup outside the table
+    lk2 = lk.copy()
+    lk2[len(lk2) // 2] = 10**9
+    with pytest.raises(hip.JfHipError, match="sorted vector has wrong length"):
+        hip.plonk_lookup_sorted_device(d_t.data_ptr(), n, rows(lk2).data_ptr(), n - 1, out.data_ptr())
