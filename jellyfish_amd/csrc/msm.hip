@@ -668,21 +668,6 @@ JF_DEV bool xyzz29_load_raw(const uint32_t* __restrict__ src, XYZZ29<Cv>& a) {  
     }
     return nz == 0;
 }
-// element idx of an array the accumulation wrote: saturated XYZZ (RAW = false) or the 29-bit kernel's raw form
-// (RAW = true: 4 L29 words, lazily reduced, all zero = identity), converted on load.  The stages after the accumulation
-// read only what they need -- one element per slice boundary, one per bucket -- instead of a conversion pass over all
-// B + 2 T elements (at 2^20 points: 65536 buckets but 393216 partial slots, 0.17 ms).
-template <class Cv, bool RAW>
-JF_DEV XYZZ<Cv> elem_load(const uint32_t* __restrict__ base, size_t idx) {
-    if constexpr (!RAW) {
-        return xyzz_load<Cv>(base + idx * (4 * Cv::Fq::N));
-    } else {
-        XYZZ29<Cv> a;
-        const bool inf = xyzz29_load_raw<Cv>(base + idx * (4 * F29<typename Cv::Fq>::L), a);
-        return xyzz29_to_std<Cv>(a, inf);
-    }
-}
-
 // rare path of the mixed add (P + P or P - P): fall back to the saturated formulas, out of line.  Everything goes
 // in and out BY VALUE: a reference would make the hot loop's accumulator escape into scratch memory.
 template <class Cv>
@@ -718,8 +703,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
                                                           uint32_t* __restrict__ partB) {
     // buckets / partA / partB are RAW here: 4 L29 words per element, lazily reduced 29-bit limbs, all zero = identity.
     // Converting to the saturated form inside flush() would put ~1400 instructions on a branch that some lane of
-    // a wave takes in half of all iterations (average bucket ~ 96 entries, 64 lanes); the fix-up and the fold convert
-    // the elements they read (elem_load<RAW>).
+    // a wave takes in half of all iterations (average bucket ~ 96 entries, 64 lanes); the fix-up, the fold and the
+    // sum tree add them in this form (Rep<Cv, true>); only the MSM's one result is converted.
     using Q = typename Cv::Fq;
     using F = F29<Q>;
     constexpr int PT = 2 * Q::N;
@@ -891,18 +876,143 @@ int32_t table_rescale(int32_t curve, uint32_t* d_pts, size_t count, int up, hipS
     return JFHIP_OK;
 }
 
+// ---- group arithmetic of the stages after the accumulation, in either representation -------------------------
+// The accumulation's runs are RAW (29-bit limbs, lazily reduced, the invariants of k_msm_accumulate29: X < 7.66 p,
+// Y < 3.66 p, ZZ, ZZZ < 1.66 p; all zero = identity).  The fix-up, the fold and the sum tree add them as they are: a full
+// XYZZ addition on the 29-bit multiplier is ~3 300 instructions against ~5 200 saturated, and no element is converted
+// before the one result of the MSM.
+template <class Cv>
+struct P29 {
+    XYZZ29<Cv> v;
+    bool inf;
+};
+
+// cold: P + P, P - P (the general formulas divide by zero there), through the complete saturated addition
+template <class Cv>
+JF_COLD P29<Cv> p29_add_rare(P29<Cv> a, P29<Cv> b) {
+    using Q = typename Cv::Fq;
+    XYZZ<Cv> x = xyzz29_to_std<Cv>(a.v, a.inf), y = xyzz29_to_std<Cv>(b.v, b.inf);
+    xyzz_add<Cv>(x, y);
+    P29<Cv> r;
+    r.inf = x.is_inf();
+    r.v.X = f29_from_fp<Q>(x.X);
+    r.v.Y = f29_from_fp<Q>(x.Y);
+    r.v.ZZ = f29_from_fp<Q>(x.ZZ);
+    r.v.ZZZ = f29_from_fp<Q>(x.ZZZ);
+    return r;
+}
+
+// acc += q (add-2008-s on XYZZ).  Bounds in multiples of p, products < 1.1 p for factors within the invariants:
+// P, R = difference + 2p < 3.1; X3 = R^2 - PPP - 2Q + 6p < 7.1; Q - X3 + 8p < 9.1 (< 10.58, the contraction limit of
+// f29_mul for BN254); Y3 = R (Q - X3 + 8p) + (2p - S1) PPP in one reduction < 1.2; ZZ3, ZZZ3 < 1.1.
+template <class Cv>
+JF_DEV void p29_add(P29<Cv>& acc, const P29<Cv>& q) {
+    using Q = typename Cv::Fq;
+    using F = F29<Q>;
+    if (q.inf) return;
+    if (acc.inf) {
+        acc = q;
+        return;
+    }
+    F zero29;
+#pragma unroll
+    for (int i = 0; i < F::L; i++) zero29.v[i] = 0;
+    const F U1 = f29_mul<Q>(acc.v.X, q.v.ZZ);
+    const F U2 = f29_mul<Q>(q.v.X, acc.v.ZZ);
+    const F S1 = f29_mul<Q>(acc.v.Y, q.v.ZZZ);
+    const F S2 = f29_mul<Q>(q.v.Y, acc.v.ZZZ);
+    const F P = f29_sub<Q, 2>(U2, U1);
+    const F PP = f29_sqr<Q>(P);
+    if (f29_mulout_is_zero<Q>(PP)) {
+        acc = p29_add_rare<Cv>(acc, q);
+        return;
+    }
+    const F R = f29_sub<Q, 2>(S2, S1);
+    const F PPP = f29_mul<Q>(P, PP);
+    const F Qv = f29_mul<Q>(U1, PP);
+    const F X3 = f29_sub3<Q, 6>(f29_sqr<Q>(R), PPP, Qv, Qv);
+    const F Y3 = f29_dot2<Q>(R, f29_sub<Q, 8>(Qv, X3), f29_sub<Q, 2>(zero29, S1), PPP);
+    acc.v.ZZ = f29_mul<Q>(f29_mul<Q>(acc.v.ZZ, q.v.ZZ), PP);
+    acc.v.ZZZ = f29_mul<Q>(f29_mul<Q>(acc.v.ZZZ, q.v.ZZZ), PPP);
+    acc.v.X = X3;
+    acc.v.Y = Y3;
+}
+
+// 2 a (dbl-2008-s-1, curve coefficient a = 0).  U = 2Y < 7.4, V = U^2 < 1.4, W = U V, S = X V < 1.1, M = 3 X^2 < 4.1,
+// X3 = M^2 - 2S + 4p < 5.1, Y3 = M (S - X3 + 6p) + (2p - W) Y < 1.3.  No point of order two exists (odd group order).
+template <class Cv>
+JF_DEV P29<Cv> p29_double(const P29<Cv>& a) {
+    using Q = typename Cv::Fq;
+    using F = F29<Q>;
+    if (a.inf) return a;
+    F zero29;
+#pragma unroll
+    for (int i = 0; i < F::L; i++) zero29.v[i] = 0;
+    const F U = f29_normalize<Q>(f29_dbl_lazy<Q>(a.v.Y));
+    const F V = f29_sqr<Q>(U);
+    const F W = f29_mul<Q>(U, V);
+    const F S = f29_mul<Q>(a.v.X, V);
+    const F X2 = f29_sqr<Q>(a.v.X);
+    const F M = f29_normalize<Q>(f29_add_lazy<Q>(X2, f29_dbl_lazy<Q>(X2)));
+    P29<Cv> r;
+    r.inf = false;
+    r.v.X = f29_sub3<Q, 4>(f29_sqr<Q>(M), S, S, zero29);
+    r.v.Y = f29_dot2<Q>(M, f29_sub<Q, 6>(S, r.v.X), f29_sub<Q, 2>(zero29, W), a.v.Y);
+    r.v.ZZ = f29_mul<Q>(V, a.v.ZZ);
+    r.v.ZZZ = f29_mul<Q>(W, a.v.ZZZ);
+    return r;
+}
+
+// the two representations behind one interface: RAW = false saturated XYZZ (4 N words), RAW = true the above (4 L words)
+template <class Cv, bool RAW>
+struct Rep;
+template <class Cv>
+struct Rep<Cv, false> {
+    using T = XYZZ<Cv>;
+    static constexpr int W = 4 * Cv::Fq::N;
+    JF_DEV static T load(const uint32_t* __restrict__ base, size_t i) { return xyzz_load<Cv>(base + i * W); }
+    JF_DEV static void store(uint32_t* __restrict__ base, size_t i, const T& a) { xyzz_store<Cv>(base + i * W, a); }
+    JF_DEV static T identity() { return XYZZ<Cv>::identity(); }
+    JF_DEV static void add(T& acc, const T& q) { xyzz_add_inl<Cv>(acc, q); }
+    JF_DEV static T dbl(const T& a) { return xyzz_double<Cv>(a); }
+    JF_DEV static XYZZ<Cv> to_std(const T& a) { return a; }
+};
+template <class Cv>
+struct Rep<Cv, true> {
+    using T = P29<Cv>;
+    static constexpr int W = 4 * F29<typename Cv::Fq>::L;
+    JF_DEV static T load(const uint32_t* __restrict__ base, size_t i) {
+        T a;
+        a.inf = xyzz29_load_raw<Cv>(base + i * W, a.v);
+        return a;
+    }
+    JF_DEV static void store(uint32_t* __restrict__ base, size_t i, const T& a) {
+        xyzz29_store_raw<Cv>(base + i * W, a.v, a.inf);
+    }
+    JF_DEV static T identity() {
+        T a;
+        a.inf = true;
+#pragma unroll
+        for (int k = 0; k < F29<typename Cv::Fq>::L; k++) a.v.X.v[k] = a.v.Y.v[k] = a.v.ZZ.v[k] = a.v.ZZZ.v[k] = 0;
+        return a;
+    }
+    JF_DEV static void add(T& acc, const T& q) { p29_add<Cv>(acc, q); }
+    JF_DEV static T dbl(const T& a) { return p29_double<Cv>(a); }
+    JF_DEV static XYZZ<Cv> to_std(const T& a) { return xyzz29_to_std<Cv>(a.v, a.inf); }
+};
+
 // buckets spanning >= 2 slices: sum their pieces.  One lane per bucket; a bucket spanning more than HEAVY_SPAN slices
 // (skewed scalars: all-equal scalars put n entries into one bucket per window = 65536 slices at 2^24, 0.8 s of serial
 // additions on one lane) is queued for k_msm_fixup_heavy instead.
 constexpr uint32_t HEAVY_SPAN = 48;
-// partA / partB: what the accumulation wrote (RAW: the 29-bit kernel's form); buckets: saturated, written here for the
-// spanning buckets only -- k_msm_bucket_fold takes every other bucket from the accumulation's own array.
+// partA / partB: what the accumulation wrote; buckets: written here for the spanning buckets only, in the same
+// representation -- k_msm_bucket_fold takes every other bucket from the accumulation's own array.
 template <class Cv, bool RAW>
 __global__ __launch_bounds__(128) void k_msm_fixup(const uint32_t* __restrict__ off, uint32_t B, uint32_t L,
                                                    const uint32_t* __restrict__ partA,
                                                    const uint32_t* __restrict__ partB,
                                                    uint32_t* __restrict__ buckets, uint32_t* __restrict__ heavy) {
-    constexpr int XZ = 4 * Cv::Fq::N;
+    using G = Rep<Cv, RAW>;
     uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     uint32_t s = off[b], e = off[b + 1];
@@ -913,12 +1023,12 @@ __global__ __launch_bounds__(128) void k_msm_fixup(const uint32_t* __restrict__ 
         heavy[1 + atomicAdd(heavy, 1u)] = b;
         return;
     }
-    XYZZ<Cv> acc = elem_load<Cv, RAW>((s % L == 0) ? partA : partB, t1);
+    typename G::T acc = G::load((s % L == 0) ? partA : partB, t1);
     for (uint32_t t = t1 + 1; t <= t2; t++) {
-        XYZZ<Cv> q = elem_load<Cv, RAW>(partA, t);
-        xyzz_add_inl<Cv>(acc, q);
+        typename G::T q = G::load(partA, t);
+        G::add(acc, q);
     }
-    xyzz_store<Cv>(buckets + (size_t)b * XZ, acc);
+    G::store(buckets, b, acc);
 }
 
 // one workgroup per queued bucket: lanes take the bucket's slices round-robin, then an LDS tree
@@ -928,30 +1038,30 @@ __global__ __launch_bounds__(256) void k_msm_fixup_heavy(const uint32_t* __restr
                                                          const uint32_t* __restrict__ partB,
                                                          uint32_t* __restrict__ buckets,
                                                          const uint32_t* __restrict__ heavy) {
-    constexpr int XZ = 4 * Cv::Fq::N;
-    __shared__ uint32_t sh[256 * XZ];
+    using G = Rep<Cv, RAW>;
+    __shared__ uint32_t sh[256 * G::W];
     const uint32_t count = heavy[0];
     for (uint32_t h = blockIdx.x; h < count; h += gridDim.x) {
         const uint32_t b = heavy[1 + h];
         const uint32_t s = off[b], e = off[b + 1];
         const uint32_t t1 = s / L, t2 = (e - 1) / L;
-        XYZZ<Cv> acc = XYZZ<Cv>::identity();
-        if (threadIdx.x == 0) acc = elem_load<Cv, RAW>((s % L == 0) ? partA : partB, t1);
+        typename G::T acc = G::identity();
+        if (threadIdx.x == 0) acc = G::load((s % L == 0) ? partA : partB, t1);
         for (uint32_t t = t1 + 1 + threadIdx.x; t <= t2; t += 256u) {
-            XYZZ<Cv> q = elem_load<Cv, RAW>(partA, t);
-            xyzz_add_inl<Cv>(acc, q);
+            typename G::T q = G::load(partA, t);
+            G::add(acc, q);
         }
-        xyzz_store<Cv>(sh + threadIdx.x * XZ, acc);
+        G::store(sh, threadIdx.x, acc);
         __syncthreads();
         for (uint32_t w = 128; w > 0; w >>= 1) {
             if (threadIdx.x < w) {
-                XYZZ<Cv> q = xyzz_load<Cv>(sh + (threadIdx.x + w) * XZ);
-                xyzz_add_inl<Cv>(acc, q);
-                xyzz_store<Cv>(sh + threadIdx.x * XZ, acc);
+                typename G::T q = G::load(sh, threadIdx.x + w);
+                G::add(acc, q);
+                G::store(sh, threadIdx.x, acc);
             }
             __syncthreads();
         }
-        if (threadIdx.x == 0) xyzz_store<Cv>(buckets + (size_t)b * XZ, acc);
+        if (threadIdx.x == 0) G::store(buckets, b, acc);
     }
 }
 
@@ -965,61 +1075,73 @@ JF_DEV XYZZ<Cv> xyzz_mul_small(const XYZZ<Cv>& p, uint32_t k) {
     }
     return r;
 }
+template <class Cv, bool RAW>
+JF_DEV typename Rep<Cv, RAW>::T rep_mul_small(const typename Rep<Cv, RAW>::T& p, uint32_t k) {
+    using G = Rep<Cv, RAW>;
+    typename G::T r = G::identity();
+    for (int bit = 31 - __clz(k | 1u); bit >= 0; bit--) {
+        r = G::dbl(r);
+        if ((k >> bit) & 1u) G::add(r, p);
+    }
+    return r;
+}
 
 // lane t folds buckets [t*g, (t+1)*g): V_t = sum_j (t*g + j + 1) * B[t*g + j].  A bucket that spans slices was summed
-// by the fix-up into `fixed` (saturated); every other one is where the accumulation left it (`acc_buckets`, RAW: the
-// 29-bit kernel's form, converted here -- independent of the running-sum chain, so it costs this latency-bound kernel
-// little).
+// by the fix-up into `fixed`; every other one is where the accumulation left it (`acc_buckets`).
 template <class Cv, bool RAW>
 __global__ __launch_bounds__(64) void k_msm_bucket_fold(const uint32_t* __restrict__ fixed,
                                                         const uint32_t* __restrict__ acc_buckets,
                                                         const uint32_t* __restrict__ off, uint32_t L, uint32_t B, uint32_t g,
                                                         uint32_t* __restrict__ out) {
-    constexpr int XZ = 4 * Cv::Fq::N;
+    using G = Rep<Cv, RAW>;
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if ((uint64_t)t * g >= B) return;
     uint32_t lo = t * g, hi = (lo + g < B) ? lo + g : B;
-    XYZZ<Cv> run = XYZZ<Cv>::identity(), sum = XYZZ<Cv>::identity();
+    typename G::T run = G::identity(), sum = G::identity();
     for (uint32_t j = hi; j-- > lo;) {
         const uint32_t s = off[j], e = off[j + 1];
         const bool spans = e > s && s / L != (e - 1) / L;
-        XYZZ<Cv> q = spans ? xyzz_load<Cv>(fixed + (size_t)j * XZ) : elem_load<Cv, RAW>(acc_buckets, j);
-        xyzz_add_inl<Cv>(run, q);
-        xyzz_add_inl<Cv>(sum, run);
+        typename G::T q = G::load(spans ? fixed : acc_buckets, j);
+        G::add(run, q);
+        G::add(sum, run);
     }
     if (lo) {
-        XYZZ<Cv> sh = xyzz_mul_small<Cv>(run, lo);
-        xyzz_add<Cv>(sum, sh);
+        typename G::T sh = rep_mul_small<Cv, RAW>(run, lo);
+        G::add(sum, sh);
     }
-    xyzz_store<Cv>(out + (size_t)t * XZ, sum);
+    G::store(out, t, sum);
 }
 
-// out[block] = sum of in[block*256*K ...): K serial loads per lane, then an LDS tree
-template <class Cv>
-__global__ __launch_bounds__(256) void k_g1_sum(const uint32_t* __restrict__ in, uint32_t m, uint32_t per_lane,
+// out[block] = sum of in[block*256*K ...): K serial loads per lane, then an LDS tree.  RAW: elements in the 29-bit form;
+// std_out: the block's sum is written as saturated XYZZ whatever the input form (the last launch of a tree)
+template <class Cv, bool RAW>
+__global__ __launch_bounds__(256) void k_g1_sum(const uint32_t* __restrict__ in, uint32_t m, uint32_t per_lane, int std_out,
                                                 uint32_t* __restrict__ out) {
-    constexpr int XZ = 4 * Cv::Fq::N;
-    __shared__ uint32_t sh[256 * XZ];
+    using G = Rep<Cv, RAW>;
+    __shared__ uint32_t sh[256 * G::W];
     uint32_t base = blockIdx.x * 256u * per_lane;
-    XYZZ<Cv> acc = XYZZ<Cv>::identity();
+    typename G::T acc = G::identity();
     for (uint32_t k = 0; k < per_lane; k++) {
         uint32_t idx = base + k * 256u + threadIdx.x;
         if (idx < m) {
-            XYZZ<Cv> q = xyzz_load<Cv>(in + (size_t)idx * XZ);
-            xyzz_add_inl<Cv>(acc, q);
+            typename G::T q = G::load(in, idx);
+            G::add(acc, q);
         }
     }
-    xyzz_store<Cv>(sh + threadIdx.x * XZ, acc);
+    G::store(sh, threadIdx.x, acc);
     __syncthreads();
     for (uint32_t s = 128; s > 0; s >>= 1) {
         if (threadIdx.x < s) {
-            XYZZ<Cv> q = xyzz_load<Cv>(sh + (threadIdx.x + s) * XZ);
-            xyzz_add_inl<Cv>(acc, q);
-            xyzz_store<Cv>(sh + threadIdx.x * XZ, acc);
+            typename G::T q = G::load(sh, threadIdx.x + s);
+            G::add(acc, q);
+            G::store(sh, threadIdx.x, acc);
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) xyzz_store<Cv>(out + (size_t)blockIdx.x * XZ, acc);
+    if (threadIdx.x == 0) {
+        if (std_out) xyzz_store<Cv>(out + (size_t)blockIdx.x * (4 * Cv::Fq::N), G::to_std(acc));
+        else G::store(out, blockIdx.x, acc);
+    }
 }
 
 // XYZZ -> packed affine + u32 infinity flag
@@ -1472,10 +1594,11 @@ int32_t srs_gen_points(int32_t curve, const uint64_t* beta_mont, const uint64_t*
     return srs_gen_t<Bls381G1>(beta_mont, g_xy, n, d_out, st);
 }
 
-template <class Cv>
+// tree of k_g1_sum launches, ping-ponging between red0 / red1; the final point -> d_out_xyzz, always saturated XYZZ.
+// RAW: d_in holds elements in the 29-bit form (Rep<Cv, true>)
+template <class Cv, bool RAW>
 static int32_t g1_sum_xyzz_t(const uint32_t* d_in, size_t count, uint32_t* d_out_xyzz, jfhip_stream* st) {
-    // tree of k_g1_sum launches, ping-ponging between red0 / red1; final point -> d_out_xyzz
-    constexpr int XZ = 4 * Cv::Fq::N;
+    constexpr int XW = Rep<Cv, RAW>::W;
     if (count == 0) {
         hipLaunchKernelGGL((k_g1_set_identity<Cv>), dim3(1), dim3(64), 0, st->s, d_out_xyzz);
         JF_HIP(hipGetLastError());
@@ -1491,11 +1614,11 @@ static int32_t g1_sum_xyzz_t(const uint32_t* d_in, size_t count, uint32_t* d_out
         if (blocks == 1) dst = d_out_xyzz;
         else {
             DevBuf& buf = flip ? st->red1 : st->red0;
-            JF_TRY(buf.ensure(blocks * XZ * 4));
+            JF_TRY(buf.ensure(blocks * XW * 4));
             dst = buf.as<uint32_t>();
         }
-        hipLaunchKernelGGL((k_g1_sum<Cv>), dim3((unsigned)blocks), dim3(256), 0, st->s, cur, (uint32_t)m, per_lane,
-                           dst);
+        hipLaunchKernelGGL((k_g1_sum<Cv, RAW>), dim3((unsigned)blocks), dim3(256), 0, st->s, cur, (uint32_t)m, per_lane,
+                           blocks == 1 ? 1 : 0, dst);
         JF_HIP(hipGetLastError());
         if (blocks == 1) break;
         cur = dst;
@@ -1564,14 +1687,15 @@ static int32_t msm_partial_t(const jfhip_srs* srs, size_t offset, const uint32_t
     JF_TRY(st->offs.ensure(((size_t)B + 1) * 4));
     JF_TRY(st->cursor.ensure(((size_t)nb + 1) * 4));
     JF_TRY(st->bsum.ensure(((size_t)nb + 1) * 4));
-    JF_TRY(st->buckets.ensure((size_t)B * XZ * 4));
+    constexpr size_t XW = 4 * F29<typename Cv::Fq>::L;   // words of a raw (29-bit form) element, >= XZ
+    JF_TRY(st->buckets.ensure((size_t)B * XW * 4));
     // fold: g buckets per lane, then a sum tree (the fold output reuses partA after the fix-up)
     // latency-bound for small bucket counts (few lanes, deep chains): short chains there
     static const int env_g = getenv("JFHIP_MSM_FOLD_G") ? atoi(getenv("JFHIP_MSM_FOLD_G")) : 0;
     uint32_t g = (B <= (1u << 17)) ? 4 : 16;
     if (env_g > 0) g = (uint32_t)env_g;
     const uint32_t Tf = (B + g - 1) / g;
-    JF_TRY(st->partA.ensure((T > Tf ? T : Tf) * XZ * 4));
+    JF_TRY(st->partA.ensure((T > Tf ? T : Tf) * XW * 4));
     JF_TRY(st->partB.ensure(T * XZ * 4));
 
     uint32_t* counts = st->counts.as<uint32_t>();
@@ -1679,7 +1803,7 @@ static int32_t msm_partial_t(const jfhip_srs* srs, size_t offset, const uint32_t
         hipLaunchKernelGGL(kern, dim3((unsigned)((T + 127) / 128)), dim3(128), 0, st->s, st->sorted.as<uint32_t>(), offs,
                            B, srs->table, (uint32_t)L, raw, rawA, rawB);
         pt.mark();
-        // the runs stay in the accumulation's raw form: the fix-up and the fold convert the elements they read
+        // the runs stay in the accumulation's raw form through the fix-up, the fold and the sum tree
         hipLaunchKernelGGL((k_msm_fixup<Cv, true>), dim3((B + 127) / 128), dim3(128), 0, st->s, offs, B, (uint32_t)L, rawA,
                            rawB, buckets, st->heavy.as<uint32_t>());
         hipLaunchKernelGGL((k_msm_fixup_heavy<Cv, true>), dim3(1024), dim3(256), 0, st->s, offs, (uint32_t)L, rawA, rawB,
@@ -1704,7 +1828,8 @@ static int32_t msm_partial_t(const jfhip_srs* srs, size_t offset, const uint32_t
     }
     JF_HIP(hipGetLastError());
     pt.mark();
-    JF_TRY(g1_sum_xyzz_t<Cv>(fold, Tf, d_out_xyzz, st));
+    if (srs->f29) JF_TRY((g1_sum_xyzz_t<Cv, true>(fold, Tf, d_out_xyzz, st)));
+    else JF_TRY((g1_sum_xyzz_t<Cv, false>(fold, Tf, d_out_xyzz, st)));
     pt.mark();
     pt.finish();
     return JFHIP_OK;
@@ -1722,7 +1847,7 @@ static int32_t g1_sum_to_affine_t(const uint32_t* d_partials, size_t count, uint
     JF_TRY(st->result.ensure(XZ * 4));
     const uint32_t* src = d_partials;
     if (count != 1) {
-        JF_TRY(g1_sum_xyzz_t<Cv>(d_partials, count, st->result.as<uint32_t>(), st));
+        JF_TRY((g1_sum_xyzz_t<Cv, false>(d_partials, count, st->result.as<uint32_t>(), st)));
         src = st->result.as<uint32_t>();
     }
     hipLaunchKernelGGL((k_g1_to_affine<Cv>), dim3(1), dim3(64), 0, st->s, src, d_out);
