@@ -589,4 +589,19 @@ JF_HD Fp<C> fp_scale_down_r29(Fp<C> x) {
     return x;
 }
 
+// x * t for a saturated, fully reduced x (x R) and a constant t kept in the 29-bit form with the factor R' (t R'):
+// the product x t R comes back saturated and fully reduced -- the data keeps its Montgomery factor, the re-slicing costs
+// ~50 instructions and the product runs on the carry-free multiplier (~280 instructions against ~320 of fp_mul).
+// f29_mul's output is < p + x t R' / R' <= p + 2^256 p / 2^(29 L) < 2 p < 2^(32 N): it fits the words and one conditional
+// subtraction reduces it.
+template <class C>
+JF_DEV Fp<C> fp_mul_const29(const Fp<C>& x, const F29<C>& t) {
+    return fp_reduce_once<C>(f29_pack_bits<C>(f29_mul<C>(f29_unpack_bits<C>(x), t)));
+}
+// a saturated Montgomery constant (t R) -> that form (t R')
+template <class C>
+JF_HD F29<C> f29_const_from_fp(const Fp<C>& t) {
+    return f29_unpack_bits<C>(fp_scale_up_r29<C>(t));
+}
+
 }  // namespace jf

@@ -20,6 +20,7 @@
 
 #include "common.hpp"
 #include "fp.hpp"
+#include "fp29.hpp"
 
 namespace jf {
 
@@ -319,13 +320,36 @@ JF_DEV void lds_put(uint4* pl, uint4* ph, uint32_t idx, const Fp<Fr>& x) {
     ph[idx] = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
 }
 
+// the w_256 table in LDS, entries in the 29-bit constant form of fp_mul_const29 (9 words: two 16-byte planes + one word)
+struct TwLds {
+    uint4* l;
+    uint4* h;
+    uint32_t* t;
+};
+template <class Fr>
+JF_DEV F29<Fr> tw29_get(const TwLds& T, uint32_t idx) {
+    static_assert(F29<Fr>::L == 9, "9-limb scalars");
+    F29<Fr> x;
+    const uint4 a = T.l[idx], b = T.h[idx];
+    x.v[0] = a.x, x.v[1] = a.y, x.v[2] = a.z, x.v[3] = a.w;
+    x.v[4] = b.x, x.v[5] = b.y, x.v[6] = b.z, x.v[7] = b.w;
+    x.v[8] = T.t[idx];
+    return x;
+}
+template <class Fr>
+JF_DEV void tw29_put(const TwLds& T, uint32_t idx, const F29<Fr>& x) {
+    T.l[idx] = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
+    T.h[idx] = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
+    T.t[idx] = x.v[8];
+}
+
 // natural-order DFT of size 4: Y[k] = sum_j b_j w4^(jk); constants come from the w_256 table in LDS
 // right where they are used (short live ranges)
 template <class Fr>
-JF_DEV void ntt_dft4(Fp<Fr>& b0, Fp<Fr>& b1, Fp<Fr>& b2, Fp<Fr>& b3, const uint4* twl, const uint4* twh) {
+JF_DEV void ntt_dft4(Fp<Fr>& b0, Fp<Fr>& b1, Fp<Fr>& b2, Fp<Fr>& b3, const TwLds& T) {
     ntt_bfly<Fr>(b0, b2);
     ntt_bfly<Fr>(b1, b3);
-    b3 = fp_mul<Fr>(b3, lds_get<Fr>(twl, twh, launder(64)));
+    b3 = fp_mul_const29<Fr>(b3, tw29_get<Fr>(T, launder(64)));
     ntt_bfly<Fr>(b0, b1);
     ntt_bfly<Fr>(b2, b3);
     Fp<Fr> t = b1;  // (Y0, Y2, Y1, Y3) -> natural order
@@ -333,12 +357,12 @@ JF_DEV void ntt_dft4(Fp<Fr>& b0, Fp<Fr>& b1, Fp<Fr>& b2, Fp<Fr>& b3, const uint4
     b2 = t;
 }
 template <class Fr>
-JF_DEV void ntt_dft8(Fp<Fr> (&a)[8], const uint4* twl, const uint4* twh) {
-    ntt_dft4<Fr>(a[0], a[2], a[4], a[6], twl, twh);
-    ntt_dft4<Fr>(a[1], a[3], a[5], a[7], twl, twh);
-    a[3] = fp_mul<Fr>(a[3], lds_get<Fr>(twl, twh, launder(32)));
-    a[5] = fp_mul<Fr>(a[5], lds_get<Fr>(twl, twh, launder(64)));
-    a[7] = fp_mul<Fr>(a[7], lds_get<Fr>(twl, twh, launder(96)));
+JF_DEV void ntt_dft8(Fp<Fr> (&a)[8], const TwLds& T) {
+    ntt_dft4<Fr>(a[0], a[2], a[4], a[6], T);
+    ntt_dft4<Fr>(a[1], a[3], a[5], a[7], T);
+    a[3] = fp_mul_const29<Fr>(a[3], tw29_get<Fr>(T, launder(32)));
+    a[5] = fp_mul_const29<Fr>(a[5], tw29_get<Fr>(T, launder(64)));
+    a[7] = fp_mul_const29<Fr>(a[7], tw29_get<Fr>(T, launder(96)));
     ntt_bfly<Fr>(a[0], a[1]);
     ntt_bfly<Fr>(a[2], a[3]);
     ntt_bfly<Fr>(a[4], a[5]);
@@ -354,16 +378,16 @@ JF_DEV void ntt_dft8(Fp<Fr> (&a)[8], const uint4* twl, const uint4* twh) {
 }
 // 2^(3-X) independent natural-order DFTs of size 2^X on registers r = digit | group << X
 template <class Fr, int X>
-JF_DEV void ntt_dft_regs(Fp<Fr> (&v)[8], const uint4* twl, const uint4* twh);
+JF_DEV void ntt_dft_regs(Fp<Fr> (&v)[8], const TwLds& T);
 
 template <class Fr, int X>
-JF_DEV void ntt_dft_regs(Fp<Fr> (&v)[8], const uint4* twl, const uint4* twh) {
+JF_DEV void ntt_dft_regs(Fp<Fr> (&v)[8], const TwLds& T) {
     static_assert(Fr::N == 8, "register-radix NTT assumes 8-limb scalars");
     if constexpr (X == 3) {
-        ntt_dft8<Fr>(v, twl, twh);
+        ntt_dft8<Fr>(v, T);
     } else if constexpr (X == 2) {
-        ntt_dft4<Fr>(v[0], v[1], v[2], v[3], twl, twh);
-        ntt_dft4<Fr>(v[4], v[5], v[6], v[7], twl, twh);
+        ntt_dft4<Fr>(v[0], v[1], v[2], v[3], T);
+        ntt_dft4<Fr>(v[4], v[5], v[6], v[7], T);
     } else if constexpr (X == 1) {
         ntt_bfly<Fr>(v[0], v[1]);
         ntt_bfly<Fr>(v[2], v[3]);
@@ -383,9 +407,12 @@ __global__ __launch_bounds__(NTT_THREADS, 2) void k_ntt_pass_r8(NttPass P) {
     constexpr int PITCH = 257;
     static_assert(DB >= 5 && DB <= 8 && XA <= 2 && LC2 >= 0 && (XA == 0 || LC3 >= 0), "digit plan");
     __shared__ uint4 xl[8 * PITCH], xh[8 * PITCH], twl[256], twh[256];
+    __shared__ uint32_t twt[256];
+    const TwLds T{twl, twh, twt};
 
     const uint32_t tid = threadIdx.x;
-    lds_put<Fr>(twl, twh, tid, fp_load<Fr>(P.t.tw_small + tid * N));
+    // every twiddle of the pass is a constant: kept in the 29-bit form, products by fp_mul_const29
+    tw29_put<Fr>(T, tid, f29_const_from_fp<Fr>(fp_load<Fr>(P.t.tw_small + tid * N)));
 
     const uint32_t d = DB;
     const uint64_t ncols = (uint64_t)P.outer << (P.log_n - d);
@@ -462,7 +489,9 @@ __global__ __launch_bounds__(NTT_THREADS, 2) void k_ntt_pass_r8(NttPass P) {
     uint32_t ld_off[8];
     uint32_t ld_idx0 = 0, ld_step = 0;  // element index inside the polynomial of register 0, step per register
     uint32_t ld_mask = 0;
-    Fp<Fr> cf0 = Fp<Fr>::zero();
+    F29<Fr> cf0;
+#pragma unroll
+    for (int i = 0; i < F29<Fr>::L; i++) cf0.v[i] = 0;
     {
         const uint64_t g = g0 + col1;
         const uint32_t j1 = ja1 + (jb1 << XA);
@@ -491,13 +520,13 @@ __global__ __launch_bounds__(NTT_THREADS, 2) void k_ntt_pass_r8(NttPass P) {
             ld_off[r] = ok ? (uint32_t)((uint64_t)poly * n + idx) : 0u;
             ld_mask |= ok ? (1u << r) : 0u;
         }
-        if (has_cf && zext && (ld_mask & 1u)) cf0 = two_level<Fr>(P.t.cl, P.t.ch, P.t.a, idx0);
+        if (has_cf && zext && (ld_mask & 1u)) cf0 = f29_const_from_fp<Fr>(two_level<Fr>(P.t.cl, P.t.ch, P.t.a, idx0));
     }
 
     // ---- store descriptors (last stage's lane layout) ---------------------------------------------
     uint32_t st_off[8];
     uint32_t st_mask = 0, tw_mask = 0;
-    Fp<Fr> tw[8];
+    F29<Fr> tw[8];
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         uint32_t k, col;
@@ -510,7 +539,8 @@ __global__ __launch_bounds__(NTT_THREADS, 2) void k_ntt_pass_r8(NttPass P) {
         }
         const uint64_t g = g0 + col;
         st_off[r] = 0;
-        tw[r] = Fp<Fr>::zero();
+#pragma unroll
+        for (int i = 0; i < F29<Fr>::L; i++) tw[r].v[i] = 0;
         if (g < ncols) {
             st_mask |= 1u << r;
             uint32_t poly;
@@ -523,7 +553,7 @@ __global__ __launch_bounds__(NTT_THREADS, 2) void k_ntt_pass_r8(NttPass P) {
                 uint64_t E = ((uint64_t)k * jrest) << log_rows;
                 if (E) {
                     tw_mask |= 1u << r;
-                    tw[r] = two_level<Fr>(P.t.tl, P.t.th, P.t.a, E);
+                    tw[r] = f29_const_from_fp<Fr>(two_level<Fr>(P.t.tl, P.t.th, P.t.a, E));
                 }
             } else {
                 uint64_t row, ob;
@@ -531,10 +561,10 @@ __global__ __launch_bounds__(NTT_THREADS, 2) void k_ntt_pass_r8(NttPass P) {
                 pos = ob + ((uint64_t)k << log_NR);
                 if (P.inverse && P.t.scale_mode == 1) {
                     tw_mask |= 1u << r;
-                    tw[r] = fp_load<Fr>(P.t.params + 2 * N);
+                    tw[r] = f29_const_from_fp<Fr>(fp_load<Fr>(P.t.params + 2 * N));
                 } else if (P.inverse && P.t.scale_mode == 2) {
                     tw_mask |= 1u << r;
-                    tw[r] = two_level<Fr, true>(P.t.cl, P.t.ch, P.t.a, pos);
+                    tw[r] = f29_const_from_fp<Fr>(two_level<Fr, true>(P.t.cl, P.t.ch, P.t.a, pos));
                 }
             }
             st_off[r] = (uint32_t)((uint64_t)poly * n + pos);
@@ -556,7 +586,7 @@ __global__ __launch_bounds__(NTT_THREADS, 2) void k_ntt_pass_r8(NttPass P) {
                     if (has_cf) v[r] = fp_mul<Fr>(v[r], two_level<Fr>(P.t.cl, P.t.ch, P.t.a, ld_idx0 + (uint32_t)r * ld_step));
                 }
             }
-            ntt_dft_regs<Fr, 3>(v, twl, twh);
+            ntt_dft_regs<Fr, 3>(v, T);
             {
                 const uint32_t fill2 = col1 >> LC2, cw = col1 & ((1u << LC2) - 1);
                 const uint32_t r2 = jb1 | (fill2 << XB);
@@ -572,7 +602,7 @@ __global__ __launch_bounds__(NTT_THREADS, 2) void k_ntt_pass_r8(NttPass P) {
             Fp<Fr> x = Fp<Fr>::zero();
             if (ld_mask & 1u) {
                 x = fp_load<Fr>(src + (size_t)ld_off[0] * N);
-                if (has_cf) x = fp_mul<Fr>(x, cf0);
+                if (has_cf) x = fp_mul_const29<Fr>(x, cf0);
             }
             lds_put<Fr>(xl, xh, tid, x);  // first pass is never final: entry = col | ja << LOGC | jb << (LOGC + XA)
             __syncthreads();
@@ -586,9 +616,9 @@ __global__ __launch_bounds__(NTT_THREADS, 2) void k_ntt_pass_r8(NttPass P) {
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             const uint32_t jb = r & (RB - 1);
-            if (jb) v[r] = fp_mul<Fr>(v[r], lds_get<Fr>(twl, twh, launder((jb * kc2) << (XA + 8 - DB))));
+            if (jb) v[r] = fp_mul_const29<Fr>(v[r], tw29_get<Fr>(T, launder((jb * kc2) << (XA + 8 - DB))));
         }
-        ntt_dft_regs<Fr, XB>(v, twl, twh);
+        ntt_dft_regs<Fr, XB>(v, T);
         if constexpr (XA > 0) {
             __syncthreads();  // exchange-1 reads done
 #pragma unroll
@@ -606,16 +636,16 @@ __global__ __launch_bounds__(NTT_THREADS, 2) void k_ntt_pass_r8(NttPass P) {
 #pragma unroll
             for (int r = 0; r < 8; r++) {
                 const uint32_t ja = r & (RA - 1);
-                if (ja) v[r] = fp_mul<Fr>(v[r], lds_get<Fr>(twl, twh, launder((ja * (kc3 + (kb3 << 3))) << (8 - DB))));
+                if (ja) v[r] = fp_mul_const29<Fr>(v[r], tw29_get<Fr>(T, launder((ja * (kc3 + (kb3 << 3))) << (8 - DB))));
             }
-            ntt_dft_regs<Fr, XA>(v, twl, twh);
+            ntt_dft_regs<Fr, XA>(v, T);
         }
         // ---- store ------------------------------------------------------------------------------------
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             if ((st_mask >> r) & 1u) {
                 Fp<Fr> x = v[r];
-                if ((tw_mask >> r) & 1u) x = fp_mul<Fr>(x, tw[r]);
+                if ((tw_mask >> r) & 1u) x = fp_mul_const29<Fr>(x, tw[r]);
                 fp_store<Fr>(dst + (size_t)st_off[r] * N, x);
             }
         }
