@@ -1177,7 +1177,7 @@ int32_t jfhip_field_op(int32_t field_id, int32_t op, const uint64_t* a, const ui
 
 int32_t jfhip_g1_op(int32_t curve_id, int32_t op, const uint64_t* P, const uint64_t* Q, uint64_t* out) {
     JF_TRY(check_curve(curve_id));
-    if (!P || !Q || !out || op < 0 || op > 1) {
+    if (!P || !Q || !out || op < 0 || op > 3) {
         set_error("bad argument");
         return JFHIP_ERR_INVALID;
     }
@@ -1187,7 +1187,7 @@ int32_t jfhip_g1_op(int32_t curve_id, int32_t op, const uint64_t* P, const uint6
     JF_TRY(st->poly_a.ensure(3 * pt));
     uint8_t* d = st->poly_a.as<uint8_t>();
     JF_HIP(hipMemcpyAsync(d, P, pt, hipMemcpyHostToDevice, st->s));
-    JF_HIP(hipMemcpyAsync(d + pt, Q, op == 0 ? pt : 32, hipMemcpyHostToDevice, st->s));
+    JF_HIP(hipMemcpyAsync(d + pt, Q, (op == 0 || op == 2) ? pt : 32, hipMemcpyHostToDevice, st->s));
     JF_TRY(g1_op_device(curve_id, op, (uint32_t*)d, (uint32_t*)(d + pt), (uint32_t*)(d + 2 * pt), st->s));
     JF_HIP(hipMemcpyAsync(out, d + 2 * pt, pt, hipMemcpyDeviceToHost, st->s));
     JF_HIP(hipStreamSynchronize(st->s));

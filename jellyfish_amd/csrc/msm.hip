@@ -1461,6 +1461,33 @@ __global__ void k_g1_op(int op, const uint32_t* __restrict__ P, const uint32_t* 
     if (op == 0) {
         Affine<Cv> q = affine_load<Cv>(Qp);
         xyzz_add_affine<Cv>(acc, q);
+    } else if (op == 2 || op == 3) {
+        // the MSM tail's group law on lazily reduced 29-bit limbs (p29_add / p29_double), same results as ops 0 / 1:
+        // op 3's 256-step double-and-add chain feeds every output back in, which is what the stated bounds must survive
+        using Q = typename Cv::Fq;
+        auto lift = [](const XYZZ<Cv>& x) {
+            P29<Cv> r;
+            r.inf = x.is_inf();
+            r.v.X = f29_from_fp<Q>(x.X);
+            r.v.Y = f29_from_fp<Q>(x.Y);
+            r.v.ZZ = f29_from_fp<Q>(x.ZZ);
+            r.v.ZZZ = f29_from_fp<Q>(x.ZZZ);
+            return r;
+        };
+        P29<Cv> a = lift(acc);
+        if (op == 2) {
+            P29<Cv> b = lift(xyzz_from_affine<Cv>(affine_load<Cv>(Qp)));
+            p29_add<Cv>(a, b);
+            acc = xyzz29_to_std<Cv>(a.v, a.inf);
+        } else {
+            Fp<Fr> k = fp_from_mont<Fr>(fp_load<Fr>(Qp));
+            P29<Cv> r = Rep<Cv, true>::identity();
+            for (int bit = 32 * Fr::N - 1; bit >= 0; bit--) {
+                r = p29_double<Cv>(r);
+                if (extract_bits<Fr::N>(k.v, bit, 1)) p29_add<Cv>(r, a);
+            }
+            acc = xyzz29_to_std<Cv>(r.v, r.inf);
+        }
     } else {
         Fp<Fr> k = fp_from_mont<Fr>(fp_load<Fr>(Qp));
         XYZZ<Cv> r = XYZZ<Cv>::identity();

@@ -477,17 +477,18 @@ def field_op(field_id: int, op: str, a, b=None) -> np.ndarray:
     return out
 
 
-def g1_add(curve: int, P, Q) -> np.ndarray:
+def g1_add(curve: int, P, Q, limbs29: bool = False) -> np.ndarray:
+    """P + Q on packed affine points; limbs29: through the MSM tail's 29-bit-limb group law (same result)."""
     P, Q = _u64(P), _u64(Q)
     out = np.zeros(2 * FQ_LIMBS64[curve], dtype=np.uint64)
-    _check(load_library().jfhip_g1_op(curve, 0, _p(P), _p(Q), _p(out)))
+    _check(load_library().jfhip_g1_op(curve, 2 if limbs29 else 0, _p(P), _p(Q), _p(out)))
     return out
 
 
-def g1_mul(curve: int, P, k_mont) -> np.ndarray:
+def g1_mul(curve: int, P, k_mont, limbs29: bool = False) -> np.ndarray:
     P, k = _u64(P), _u64(k_mont)
     out = np.zeros(2 * FQ_LIMBS64[curve], dtype=np.uint64)
-    _check(load_library().jfhip_g1_op(curve, 1, _p(P), _p(k), _p(out)))
+    _check(load_library().jfhip_g1_op(curve, 3 if limbs29 else 1, _p(P), _p(k), _p(out)))
     return out
 
 

@@ -61,6 +61,34 @@ def test_group_ops(hip, cv):
     assert pt_from(cv, hip.g1_mul(cv.curve_id, G, rm1)) == R.ec_neg(cv, cv.g)
 
 
+@pytest.mark.parametrize("cv", CURVES, ids=lambda c: c.name)
+def test_group_ops_29bit_limbs(hip, cv):
+    """The MSM tail's group law on lazily reduced 29-bit limbs (csrc/msm.hip p29_add / p29_double) against the oracle:
+    the rare branches (P + P, P - P, identity on either side) and 256-step double-and-add chains whose every output is
+    fed back in, which is where a lazy-reduction bound that is too optimistic would show."""
+    cid = cv.curve_id
+    G = pt_arr(cv, cv.g)
+    zero = np.zeros_like(G)
+    neg = pt_arr(cv, R.ec_neg(cv, cv.g))
+    assert (hip.g1_add(cid, G, G, limbs29=True) == hip.g1_add(cid, G, G)).all()
+    assert pt_from(cv, hip.g1_add(cid, G, neg, limbs29=True)) is None
+    assert (hip.g1_add(cid, G, zero, limbs29=True) == G).all()
+    assert (hip.g1_add(cid, zero, G, limbs29=True) == G).all()
+    rng = R.SplitMix64(77)
+    scal = [1, 2, 3, cv.fr.p - 1, cv.fr.p - 2, (1 << 200) - 1] + [rng.field(cv.fr) for _ in range(6)]
+    pts = []
+    for s in scal:
+        sm = mont_arr(cv.fr, [s])[0]
+        got = hip.g1_mul(cid, G, sm, limbs29=True)
+        assert (got == C.ec_mul(cid, G, sm)).all(), hex(s)
+        pts.append(got)
+    for a, b in zip(pts, pts[1:]):
+        assert (hip.g1_add(cid, a, b, limbs29=True) == C.ec_add(cid, a, b)).all()
+    # a chain on a random base point rather than the generator
+    sm = mont_arr(cv.fr, [scal[-1]])[0]
+    assert (hip.g1_mul(cid, pts[-2], sm, limbs29=True) == C.ec_mul(cid, pts[-2], sm)).all()
+
+
 @pytest.mark.parametrize("fname", list(FIELD_ID))
 def test_unsaturated_29bit_arithmetic(hip, fname):
     """csrc/fp29.hpp (29-bit limbs, lazy reduction, R' = 2^(29 L)) agrees with the saturated arithmetic / the oracle
