@@ -91,6 +91,9 @@ int32_t jfhip_stream_wrap(void *hip_stream, jfhip_stream **out);
  * arkworks' `infinity: bool`.  The library packs the points, uploads them once and
  * precomputes the window multiples 2^(c*w) * P_i it needs (kept in HBM; sized for 288 GB),
  * so later commits need no per-window combine.  window_bits = 0 lets the library choose.
+ * An MSM that ends at or below n / 16 (a small circuit against a universal SRS) runs on a second, smaller window table
+ * over a prefix of the points, built on the first such call and owned by the handle (< 1/8 of the main table in all;
+ * environment JFHIP_SRS_PREFIX=0 disables it).  Results do not depend on which table runs.
  * n == 0 is JFHIP_ERR_INVALID (reference :772-778 rejects supported_degree > len-1). */
 int32_t jfhip_srs_load(int32_t curve_id, const void *points, size_t n, size_t stride_bytes, int32_t window_bits,
                        jfhip_srs **out);

@@ -441,6 +441,7 @@ int32_t jfhip_srs_gen_for_testing(int32_t curve_id, const uint64_t* beta_mont, c
 
 int32_t jfhip_srs_free(jfhip_srs* srs) {
     if (!srs) return JFHIP_OK;
+    for (jfhip_srs* p : srs->prefixes) (void)jfhip_srs_free(p);
     if (srs->table) (void)hipFree(srs->table);
     delete srs;
     return JFHIP_OK;
@@ -487,6 +488,45 @@ static int32_t check_msm_range(const jfhip_srs* srs, size_t offset, size_t n) {
     return JFHIP_OK;
 }
 
+// An MSM over points [offset, offset + n) with offset + n <= srs->n / 16 runs on a window table of its own over the
+// first 4096 * 4^k >= offset + n points, built on the first such call and kept with the handle (all levels together
+// stay below ~1/8 of the main table).  The handle's window_bits are chosen for srs->n: a 2^12-term commitment against a
+// 2^24-point universal SRS would clear, scan and fold 2^21 buckets for 4096 x 12 additions.  JFHIP_SRS_PREFIX=0 turns
+// it off.  If the table cannot be built (out of memory) the MSM runs on the main table as before.
+static const jfhip_srs* srs_route(const jfhip_srs* srs, size_t end, jfhip_stream* st) {
+    static const bool on = [] {
+        const char* e = getenv("JFHIP_SRS_PREFIX");
+        return !(e && e[0] == '0');
+    }();
+    if (!on || srs->n < ((size_t)1 << 14) || end == 0 || end > srs->n / 16) return srs;
+    size_t want = 4096;
+    while (want < end) want <<= 2;
+    if (want > srs->n / 4) return srs;
+    std::lock_guard<std::mutex> lk(srs->prefix_mu);
+    for (const jfhip_srs* p : srs->prefixes)
+        if (p->n == want) return p;
+    jfhip_srs* p = nullptr;
+    if (srs_alloc(srs->curve, want, 0, &p) != JFHIP_OK) {
+        (void)hipGetLastError();  // the failed allocation must not surface at the MSM's next launch check
+        return srs;
+    }
+    p->device = srs->device;
+    const size_t pt = 2 * (size_t)fq_bytes(srs->curve);
+    // window 0 of the main table = the points themselves, possibly with the kernels' internal Montgomery factor
+    bool ok = hipMemcpyAsync(p->table, srs->table, want * pt, hipMemcpyDeviceToDevice, st->s) == hipSuccess;
+    if (ok && srs->f29) ok = table_rescale(srs->curve, p->table, want, 0, st->s) == JFHIP_OK;
+    if (ok) ok = srs_build_table(p, p->table, st) == JFHIP_OK;
+    // other host threads pick the table up without any ordering on this stream
+    if (ok) ok = hipStreamSynchronize(st->s) == hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError();
+        (void)jfhip_srs_free(p);
+        return srs;
+    }
+    srs->prefixes.push_back(p);
+    return p;
+}
+
 int32_t jfhip_msm_partial_device(const jfhip_srs* srs, size_t offset, const void* d_scalars, size_t n,
                                  void* d_out_xyzz, jfhip_stream* stream) {
     JF_TRY(check_msm_range(srs, offset, n));
@@ -496,14 +536,16 @@ int32_t jfhip_msm_partial_device(const jfhip_srs* srs, size_t offset, const void
     }
     JF_STREAM(st, stream);
     std::lock_guard<std::mutex> lk(st->mu);
-    return msm_partial_device(srs, offset, (const uint32_t*)d_scalars, n, (uint32_t*)d_out_xyzz, st);
+    return msm_partial_device(srs_route(srs, offset + n, st), offset, (const uint32_t*)d_scalars, n,
+                              (uint32_t*)d_out_xyzz, st);
 }
 
 static int32_t msm_device_locked(const jfhip_srs* srs, size_t offset, const void* d_scalars, size_t n, void* d_out,
                                  jfhip_stream* st) {
     const size_t xz = 4 * (size_t)fq_bytes(srs->curve);
     JF_TRY(st->result.ensure(xz + 256));
-    JF_TRY(msm_partial_device(srs, offset, (const uint32_t*)d_scalars, n, st->result.as<uint32_t>(), st));
+    JF_TRY(msm_partial_device(srs_route(srs, offset + n, st), offset, (const uint32_t*)d_scalars, n,
+                              st->result.as<uint32_t>(), st));
     return g1_sum_to_affine(srs->curve, st->result.as<uint32_t>(), 1, (uint32_t*)d_out, st);
 }
 

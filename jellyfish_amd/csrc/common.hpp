@@ -162,6 +162,10 @@ struct jfhip_srs {
     int device = 0;
     uint32_t* table = nullptr;  // [W][n] packed affine, entry (w, i) = 2^(c*w) * P_i
     bool f29 = false;           // table coordinates carry the Montgomery factor 2^(29 L) of fp29.hpp instead of 2^(32 N)
+    // window tables over a prefix of the points with window_bits chosen for THAT length, built on the first MSM that is
+    // much shorter than the SRS (api.hip srs_route): the handle's own table would make it clear and fold 2^(c-1) buckets
+    mutable std::mutex prefix_mu;
+    mutable std::vector<jfhip_srs*> prefixes;
 };
 
 namespace jf {

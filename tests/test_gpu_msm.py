@@ -169,6 +169,30 @@ def test_msm_full_size_closed_form(hip):
 
 
 @pytest.mark.parametrize("cv", CURVES, ids=lambda c: c.name)
+def test_short_msm_on_a_large_srs(hip, cv):
+    """Commitments much shorter than the SRS (a small circuit against a universal SRS) run on a window table over a
+    prefix of the points, built on first use (csrc/api.hip srs_route): lengths below and above the n / 16 threshold,
+    both prefix levels (4096, 16384), an offset slice, and the identity, against the oracle."""
+    n = (1 << 18) + 5
+    beta = mont_arr(cv.fr, [0x51A0 + cv.curve_id])[0]
+    srs = hip.Srs.gen_for_testing(cv.curve_id, beta, pt_arr(cv, cv.g), n)
+    host = srs.read(0, 21000)
+    for rnd, (off, m) in enumerate([(0, 1), (0, 700), (0, 4096), (0, 5000), (100, 3000), (0, 16384), (0, 20000),
+                                    (0, 700)]):
+        sc = rand_fr_mont(cv, m, 900 + rnd)
+        out, inf = hip.msm(srs, sc, offset=off)
+        assert (out == C.msm(cv.curve_id, host[off:off + m], sc)).all(), (off, m)
+        assert not inf
+    out, inf = hip.msm(srs, np.zeros((300, 4), dtype=np.uint64))
+    assert inf and not out.any()
+    polys = [rand_fr_mont(cv, m, 950 + m) for m in (33, 1025, 4097)]
+    outs, _ = hip.msm_batch(srs, polys)
+    for i, pl in enumerate(polys):
+        assert (outs[i] == C.msm(cv.curve_id, host[:len(pl)], pl)).all()
+    srs.free()
+
+
+@pytest.mark.parametrize("cv", CURVES, ids=lambda c: c.name)
 @pytest.mark.parametrize("limbs29", ["1", "0"], ids=["limbs29", "saturated"])
 def test_msm_skewed_scalars_both_accumulators(hip, cv, limbs29, monkeypatch):
     """Scalar distributions that put most entries into a few buckets (all equal, 0/1 witnesses, one heavy value among
