@@ -382,6 +382,7 @@ int32_t jfhip_witness_gather_device(const void *d_witness, size_t num_vars, cons
  * op: 0 add, 1 sub, 2 mul, 3 neg(a), 4 inv(a) (inv(0)=0), 5 from_mont(a), 6 to_mont(a);
  *     7 mul, 8 square(a), 9 sub, 10 ((ab - 2a)(a^2 - b))b - ab, 11 ab + (a^2 - b)b computed in the kernels' internal
  *     unsaturated 29-bit-limb form (csrc/fp29.hpp) and converted back: same results as the saturated ops.
+ *     12, 13: inv(a) by the kernels' two Euclid-type routines (batched division steps; binary): same results as op 4.
  * Host arrays of n elements; exercises the same device arithmetic the MSM/NTT kernels use. */
 int32_t jfhip_field_op(int32_t field_id, int32_t op, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n);
 

@@ -1193,12 +1193,12 @@ int32_t jfhip_witness_gather_device(const void* d_witness, size_t num_vars, cons
 // ---- field / group test surface ---------------------------------------------------------------------
 
 int32_t jfhip_field_op(int32_t field_id, int32_t op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
-    if (field_id < 0 || field_id > 3 || op < 0 || op > 11) {
+    if (field_id < 0 || field_id > 3 || op < 0 || op > 13) {
         set_error("bad field id / op");
         return JFHIP_ERR_INVALID;
     }
     if (n == 0) return JFHIP_OK;
-    if (!a || !out || ((op <= 2 || op >= 7) && !b)) {
+    if (!a || !out || ((op <= 2 || (op >= 7 && op <= 11)) && !b)) {
         set_error("null argument");
         return JFHIP_ERR_INVALID;
     }
@@ -1209,7 +1209,7 @@ int32_t jfhip_field_op(int32_t field_id, int32_t op, const uint64_t* a, const ui
     JF_TRY(st->poly_b.ensure(n * el));
     JF_TRY(st->poly_c.ensure(n * el));
     JF_HIP(hipMemcpyAsync(st->poly_a.p, a, n * el, hipMemcpyHostToDevice, st->s));
-    if (op <= 2 || op >= 7) JF_HIP(hipMemcpyAsync(st->poly_b.p, b, n * el, hipMemcpyHostToDevice, st->s));
+    if (b) JF_HIP(hipMemcpyAsync(st->poly_b.p, b, n * el, hipMemcpyHostToDevice, st->s));
     JF_TRY(field_op_device(field_id, op, st->poly_a.as<uint32_t>(), st->poly_b.as<uint32_t>(),
                            st->poly_c.as<uint32_t>(), n, st->s));
     JF_HIP(hipMemcpyAsync(out, st->poly_c.p, n * el, hipMemcpyDeviceToHost, st->s));

@@ -186,7 +186,7 @@ JF_COLD Affine<Cv> xyzz_to_affine(const XYZZ<Cv>& p) {
         r.y = Fp<Q>::zero();
         return r;
     }
-    auto t = fp_inv_binary<Q>(fp_mul<Q>(p.ZZ, p.ZZZ));
+    auto t = fp_inv_safegcd<Q>(fp_mul<Q>(p.ZZ, p.ZZZ));
     r.x = fp_mul<Q>(p.X, fp_mul<Q>(t, p.ZZZ));
     r.y = fp_mul<Q>(p.Y, fp_mul<Q>(t, p.ZZ));
     return r;

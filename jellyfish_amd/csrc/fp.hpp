@@ -430,8 +430,9 @@ __device__ __noinline__ Fp<C> fp_inv(const Fp<C>& a) {
 }
 
 // Binary extended Euclid on the raw integers (HAC 14.61 shape): ~2*bits iterations of shifts and
-// subtractions instead of ~1.5*bits Montgomery products -- about 4x faster than the Fermat ladder
-// for the one-lane normalisation at the end of every MSM.  Input/output in Montgomery form:
+// subtractions instead of ~1.5*bits Montgomery products.  Round 1's normalisation; the kernels now call
+// fp_inv_safegcd below (7x faster on one lane, 40x in throughput: the branches here diverge across a wave), this one
+// stays as a second opinion on the test surface (jfhip_field_op 13).  Input/output in Montgomery form:
 // inv(aR) = a^-1 R^-1, lifted back with two multiplications by R^2.  inv(0) = 0.
 template <class C>
 __device__ __noinline__ Fp<C> fp_inv_binary(const Fp<C>& a) {
@@ -522,6 +523,166 @@ __device__ __noinline__ Fp<C> fp_inv_binary(const Fp<C>& a) {
     for (int i = 0; i < N; i++) r.v[i] = pick_u ? x1[i] : x2[i];
     r = fp_mul<C>(r, Fp<C>::r2());
     return fp_mul<C>(r, Fp<C>::r2());
+}
+
+// ---- inversion by batched division steps (Bernstein-Yang "safegcd", the shape of 30-bit signed-limb implementations) ---
+// 30 division steps at a time are decided on the low 32 bits of (f, g) alone and collected in a 2 x 2 integer matrix
+// T = [[u, v], [q, r]] with 2^30 (f', g') = T (f, g); the matrix is then applied once to the full-width (f, g) (exact
+// division by 2^30) and to (d, e) modulo p (a multiple of p makes the low 30 bits vanish), which keep d a = f, e a = g
+// (mod p).  g reaches 0 after at most (49 bits + 57) / 17 steps with f = +-1, so a^-1 = +-d.  About 12 instructions per
+// step on 32-bit registers plus ~250 per batch, against ~70 per bit stripped for the binary Euclid above, and no
+// data-dependent branch inside a batch (measured, scripts/inv_bench.py: one BN254 Fq inversion on one lane 0.15 ->
+// 0.02 ms, 2^18 of them 0.85 -> 0.02 ms).  Values are signed, 30 bits per limb, the top limb carrying the sign.
+template <class C>
+struct Inv30 {
+    static constexpr int BITS = 32 * C::N;
+    static constexpr int NL = (BITS + 2 + 29) / 30;            // room for (-2p, p) and |f|, |g| <= 2^BITS
+    static constexpr int MAX_BATCHES = ((49 * BITS + 57) / 17 + 29) / 30 + 1;
+    JF_HD static constexpr int32_t plimb(int i) {              // limb i of p, 30 bits each
+        const int bit = 30 * i, w = bit / 32, sh = bit % 32;
+        uint64_t lo = w < C::N ? C::P(w) : 0u;
+        uint64_t hi = (w + 1) < C::N ? C::P(w + 1) : 0u;
+        return (int32_t)(((lo | (hi << 32)) >> sh) & 0x3fffffffu);
+    }
+    JF_HD static constexpr uint32_t pinv30() {                 // p^-1 mod 2^30 (Newton on the low word, p odd)
+        uint32_t p0 = C::P(0), x = p0;                         // 3 correct bits
+        for (int k = 0; k < 5; k++) x *= 2u - p0 * x;
+        return x & 0x3fffffffu;
+    }
+};
+
+template <class C>
+__device__ __noinline__ Fp<C> fp_inv_safegcd(const Fp<C>& a) {
+    using I = Inv30<C>;
+    constexpr int N = C::N, NL = I::NL;
+    constexpr int32_t M30 = 0x3fffffff;
+    if (a.is_zero()) return a;
+    int32_t f[NL], g[NL], d[NL], e[NL];
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        const int bit = 30 * i, w = bit / 32, sh = bit % 32;
+        uint32_t lo = 0, hi = 0;
+#pragma unroll
+        for (int k = 0; k < N; k++) {   // static indices only
+            lo = (k == w) ? a.v[k] : lo;
+            hi = (k == w + 1) ? a.v[k] : hi;
+        }
+        const uint64_t two = (uint64_t)lo | ((uint64_t)hi << 32);
+        f[i] = I::plimb(i);
+        g[i] = (int32_t)((two >> sh) & 0x3fffffffu);
+        d[i] = 0;
+        e[i] = (i == 0) ? 1 : 0;
+    }
+    int32_t delta = 1;
+    for (int batch = 0; batch < I::MAX_BATCHES; batch++) {
+        uint32_t gz = 0;
+#pragma unroll
+        for (int i = 0; i < NL; i++) gz |= (uint32_t)g[i];
+        if (gz == 0) break;
+        // 30 division steps on the low words
+        uint32_t f0 = (uint32_t)f[0] | ((uint32_t)f[1] << 30), g0 = (uint32_t)g[0] | ((uint32_t)g[1] << 30);
+        int32_t u = 1, v = 0, q = 0, r = 1;
+        for (int k = 0; k < 30; k++) {
+            const bool odd = g0 & 1u;
+            const bool swap = odd && delta > 0;
+            const uint32_t addf = odd ? (swap ? 0u - f0 : f0) : 0u;
+            const int32_t addu = odd ? (swap ? -u : u) : 0, addv = odd ? (swap ? -v : v) : 0;
+            const uint32_t nf = swap ? g0 : f0;
+            const int32_t nu = swap ? q : u, nv = swap ? r : v;
+            g0 = (g0 + addf) >> 1;
+            q += addu;
+            r += addv;
+            f0 = nf;
+            u = 2 * nu;
+            v = 2 * nv;
+            delta = swap ? 1 - delta : 1 + delta;
+        }
+        // (f, g) <- T (f, g) / 2^30, exactly
+        {
+            int64_t cf = (int64_t)u * f[0] + (int64_t)v * g[0];
+            int64_t cg = (int64_t)q * f[0] + (int64_t)r * g[0];
+            cf >>= 30;
+            cg >>= 30;
+#pragma unroll
+            for (int i = 1; i < NL; i++) {
+                cf += (int64_t)u * f[i] + (int64_t)v * g[i];
+                cg += (int64_t)q * f[i] + (int64_t)r * g[i];
+                f[i - 1] = (int32_t)cf & M30;
+                g[i - 1] = (int32_t)cg & M30;
+                cf >>= 30;
+                cg >>= 30;
+            }
+            f[NL - 1] = (int32_t)cf;
+            g[NL - 1] = (int32_t)cg;
+        }
+        // (d, e) <- T (d, e) / 2^30 mod p; d, e stay in (-2p, p)
+        {
+            const int32_t sd = d[NL - 1] >> 31, se = e[NL - 1] >> 31;
+            int32_t md = (u & sd) + (v & se), me = (q & sd) + (r & se);
+            int64_t cd = (int64_t)u * d[0] + (int64_t)v * e[0];
+            int64_t ce = (int64_t)q * d[0] + (int64_t)r * e[0];
+            md -= (int32_t)((I::pinv30() * (uint32_t)cd + (uint32_t)md) & (uint32_t)M30);
+            me -= (int32_t)((I::pinv30() * (uint32_t)ce + (uint32_t)me) & (uint32_t)M30);
+            cd += (int64_t)I::plimb(0) * md;
+            ce += (int64_t)I::plimb(0) * me;
+            cd >>= 30;
+            ce >>= 30;
+#pragma unroll
+            for (int i = 1; i < NL; i++) {
+                cd += (int64_t)u * d[i] + (int64_t)v * e[i] + (int64_t)I::plimb(i) * md;
+                ce += (int64_t)q * d[i] + (int64_t)r * e[i] + (int64_t)I::plimb(i) * me;
+                d[i - 1] = (int32_t)cd & M30;
+                e[i - 1] = (int32_t)ce & M30;
+                cd >>= 30;
+                ce >>= 30;
+            }
+            d[NL - 1] = (int32_t)cd;
+            e[NL - 1] = (int32_t)ce;
+        }
+    }
+    // f = +-1: a^-1 = d f.  Bring it from (-2p, 2p) into [0, p).
+    const bool fneg = f[NL - 1] < 0;
+    int64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        c += fneg ? -(int64_t)d[i] : (int64_t)d[i];
+        d[i] = (i < NL - 1) ? ((int32_t)c & M30) : (int32_t)c;
+        if (i < NL - 1) c >>= 30;
+    }
+    for (int round = 0; round < 2; round++) {   // + p while negative
+        if (d[NL - 1] >= 0) break;
+        c = 0;
+#pragma unroll
+        for (int i = 0; i < NL; i++) {
+            c += (int64_t)d[i] + I::plimb(i);
+            d[i] = (i < NL - 1) ? ((int32_t)c & M30) : (int32_t)c;
+            if (i < NL - 1) c >>= 30;
+        }
+    }
+    for (int round = 0; round < 2; round++) {   // - p while >= p
+        int32_t t[NL];
+        c = 0;
+#pragma unroll
+        for (int i = 0; i < NL; i++) {
+            c += (int64_t)d[i] - I::plimb(i);
+            t[i] = (i < NL - 1) ? ((int32_t)c & M30) : (int32_t)c;
+            if (i < NL - 1) c >>= 30;
+        }
+        if (t[NL - 1] < 0) break;
+#pragma unroll
+        for (int i = 0; i < NL; i++) d[i] = t[i];
+    }
+    Fp<C> res;
+#pragma unroll
+    for (int w = 0; w < N; w++) {   // word w = bits [32 w, 32 w + 32)
+        const int i0 = (32 * w) / 30, s0 = (32 * w) % 30;
+        uint64_t t = (uint64_t)(uint32_t)d[i0] >> s0;
+        if (i0 + 1 < NL) t |= (uint64_t)(uint32_t)d[i0 + 1] << (30 - s0);
+        if (i0 + 2 < NL) t |= (uint64_t)(uint32_t)d[i0 + 2] << (60 - s0);
+        res.v[w] = (uint32_t)t;
+    }
+    res = fp_mul<C>(res, Fp<C>::r2());
+    return fp_mul<C>(res, Fp<C>::r2());
 }
 
 // small-exponent power

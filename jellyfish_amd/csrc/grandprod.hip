@@ -53,7 +53,7 @@ __global__ __launch_bounds__(128) void k_gp_perm_ratio(uint32_t n, uint32_t nw, 
         pre[k] = prod;
         prod = fp_mul<Fr>(prod, b);
     }
-    Fp<Fr> inv = fp_inv_binary<Fr>(prod);  // a zero denominator (probability ~ n/r) gives 0, as F::inverse-less division would panic
+    Fp<Fr> inv = fp_inv_safegcd<Fr>(prod);  // a zero denominator (probability ~ n/r) gives 0, as F::inverse-less division would panic
 #pragma unroll
     for (int k = GP_INV_CHUNK - 1; k >= 0; k--) {
         const uint64_t j = j0 + k;
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(128) void k_gp_lookup_ratio(uint32_t n, const uint3
         pre[k] = prod;
         prod = fp_mul<Fr>(prod, b);
     }
-    Fp<Fr> inv = fp_inv_binary<Fr>(prod);
+    Fp<Fr> inv = fp_inv_safegcd<Fr>(prod);
 #pragma unroll
     for (int k = GP_INV_CHUNK - 1; k >= 0; k--) {
         const uint64_t j = j0 + k;
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void k_gp_perm_terms(uint32_t n, uint32_t nw, 
 }
 template <class Fr>
 __global__ void k_gp_inv_one(const uint32_t* __restrict__ in, uint32_t* __restrict__ out) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) fp_store<Fr>(out, fp_inv_binary<Fr>(fp_load<Fr>(in)));
+    if (threadIdx.x == 0 && blockIdx.x == 0) fp_store<Fr>(out, fp_inv_safegcd<Fr>(fp_load<Fr>(in)));
 }
 template <class Fr>
 __global__ __launch_bounds__(256) void k_gp_perm_combine(uint32_t n, const uint32_t* __restrict__ pa,

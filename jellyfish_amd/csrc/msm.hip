@@ -1236,7 +1236,7 @@ __global__ __launch_bounds__(128) void k_srs_table(uint32_t* __restrict__ table,
         fp_store<Q>(pre + ((size_t)(w - 1) * m + k) * NQ, prod);
         prod = fp_mul<Q>(prod, zeff);
     }
-    Fp<Q> inv = fp_inv<Q>(prod);
+    Fp<Q> inv = fp_inv_safegcd<Q>(prod);
     for (int w = W - 1; w >= 1; w--) {
         Fp<Q> z = fp_load<Q>(zs + ((size_t)(w - 1) * m + k) * NQ);
         Fp<Q> pr = fp_load<Q>(pre + ((size_t)(w - 1) * m + k) * NQ);

@@ -406,6 +406,8 @@ __global__ __launch_bounds__(128) void k_field_op(int op, const uint32_t* __rest
     case 3: r = fp_neg<C>(x); break;
     case 4: r = fp_inv<C>(x); break;
     case 5: r = fp_from_mont<C>(x); break;
+    case 12: r = fp_inv_safegcd<C>(x); break;   // the inversion of the normalisation / batch-inversion kernels
+    case 13: r = fp_inv_binary<C>(x); break;
     // 29-bit-limb arithmetic of fp29.hpp, through the conversions (test surface)
     case 7: r = f29_to_fp<C>(f29_mul<C>(f29_from_fp<C>(x), f29_from_fp<C>(y))); break;
     case 8: r = f29_to_fp<C>(f29_sqr<C>(f29_from_fp<C>(x))); break;

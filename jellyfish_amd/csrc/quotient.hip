@@ -96,7 +96,7 @@ __global__ __launch_bounds__(128) void k_quot_inv_den(const uint32_t* __restrict
         pre[k] = prod;
         prod = fp_mul<Fr>(prod, den[k]);
     }
-    Fp<Fr> inv = fp_inv_binary<Fr>(prod);
+    Fp<Fr> inv = fp_inv_safegcd<Fr>(prod);
 #pragma unroll
     for (int k = INV_CHUNK - 1; k >= 0; k--) {
         Fp<Fr> r = fp_mul<Fr>(inv, pre[k]);
@@ -114,7 +114,7 @@ __global__ void k_quot_zh_inv(const uint32_t* __restrict__ lo, const uint32_t* _
     Fp<Fr> x = fp_mul<Fr>(coset_offset<Fr>(gen), root_pow<Fr>(lo, hi, a, i));
     for (uint32_t k = 0; k < log_n; k++) x = fp_sqr<Fr>(x);
     x = fp_sub<Fr>(x, Fp<Fr>::one());
-    fp_store<Fr>(zh_inv + (size_t)i * Fr::N, fp_inv_binary<Fr>(x));
+    fp_store<Fr>(zh_inv + (size_t)i * Fr::N, fp_inv_safegcd<Fr>(x));
 }
 
 // in: k[6], alpha, beta, gamma, tau, alpha_base  ->  derived constants (QC_* slots)

@@ -463,7 +463,9 @@ def poly_lincomb_device(curve: int, d_polys, lens, coeffs_mont, d_out: int, n: i
 
 FIELD_OPS = {"add": 0, "sub": 1, "mul": 2, "neg": 3, "inv": 4, "from_mont": 5, "to_mont": 6,
              # unsaturated 29-bit-limb arithmetic of csrc/fp29.hpp through its conversions (test surface)
-             "mul29": 7, "sqr29": 8, "sub29": 9, "chain29": 10, "dot29": 11}
+             "mul29": 7, "sqr29": 8, "sub29": 9, "chain29": 10, "dot29": 11,
+             # the two Euclid-type inversions of csrc/fp.hpp (division steps in batches of 30; binary)
+             "inv_safegcd": 12, "inv_binary": 13}
 
 
 def field_op(field_id: int, op: str, a, b=None) -> np.ndarray:

@@ -33,6 +33,11 @@ def test_field_ops_golden_and_random(hip, fname):
         assert (hip.field_op(fid, op, A, B) == C.fp_binop(fid, op, A, B)).all(), op
     assert (hip.field_op(fid, "neg", A) == C.fp_unop(fid, "neg", A)).all()
     assert (hip.field_op(fid, "inv", A[:256]) == C.fp_unop(fid, "inv", A[:256])).all()
+    # the Euclid-type inversions the kernels use (normalisation of every MSM result, batch inversions): edge values too
+    E = mont_arr(f, [0, 1, 2, f.p - 1, f.p - 2, (f.p - 1) // 2, (f.p + 1) // 2, 1 << 200, (1 << 253) - 1] + xs[:2039])
+    want = C.fp_unop(fid, "inv", E)
+    assert (hip.field_op(fid, "inv_safegcd", E) == want).all()
+    assert (hip.field_op(fid, "inv_binary", E) == want).all()
     assert (hip.field_op(fid, "from_mont", A) == C.fp_unop(fid, "from_mont", A)).all()
     assert (hip.field_op(fid, "to_mont", A) == C.fp_unop(fid, "to_mont", A)).all()
     # outputs fully reduced
