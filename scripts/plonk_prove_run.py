@@ -41,3 +41,14 @@ for _ in range(runs):
     JP.PlonkKzgSnark.prove(rng, cs, pk, witness_mont=wit)
     torch.cuda.synchronize()
     print("prove %.2f ms" % ((time.perf_counter() - t0) * 1e3), JP.PROFILE or "", flush=True)
+if os.environ.get("JF_HOST_PROFILE"):
+    # host side of one proof under cProfile: where the Python time between device rounds goes
+    import cProfile
+    import pstats
+
+    pr = cProfile.Profile()
+    pr.enable()
+    JP.PlonkKzgSnark.prove(rng, cs, pk, witness_mont=wit)
+    torch.cuda.synchronize()
+    pr.disable()
+    pstats.Stats(pr).sort_stats("tottime").print_stats(28)

@@ -11,12 +11,25 @@ c = sqlite3.connect(sys.argv[1])
 cols = [r[1] for r in c.execute("pragma table_info(kernels)")]
 q = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else "0")
 rows = c.execute("select name, start, end, %s from kernels order by start" % q).fetchall()
-idx = [i for i, r in enumerate(rows) if "k_witness_gather" in r[0]]
+idx = [i for i, r in enumerate(rows) if "k_gather_rows32" in r[0]]
 seg = rows[idx[-1]:] if idx else rows[len(rows) * 2 // 3:]
 t0 = seg[0][1]
 for nm, s, e, qid in seg:
     if e - s >= 40000:
         print("%8.3f %8.3f  +%6.3f  q%-3s %s" % ((s - t0) / 1e6, (e - t0) / 1e6, (e - s) / 1e6, qid, nm.split("(")[0].replace("void jf::", "")[:60]))
+# device idle time: gaps in the union of all kernel intervals (host syncs, read-backs, launch latency)
+ivs = sorted((s, e, nm) for nm, s, e, _ in seg)
+cur_end, cur_nm, gaps = ivs[0][1], ivs[0][2], []
+for s, e, nm in ivs[1:]:
+    if s > cur_end:
+        gaps.append((s - cur_end, (cur_end - t0) / 1e6, cur_nm, nm))
+    if e > cur_end:
+        cur_end, cur_nm = e, nm
+short = lambda x: x.split("(")[0].replace("void jf::", "")[:40]
+print("idle: %.3f ms in %d gaps (span %.3f ms); gaps >= 30 us:" % (sum(g[0] for g in gaps) / 1e6, len(gaps), (cur_end - t0) / 1e6))
+for g in sorted(gaps, key=lambda g: -g[0]):
+    if g[0] >= 30000:
+        print("  %7.3f ms at %8.3f  after %-40s before %s" % (g[0] / 1e6, g[1], short(g[2]), short(g[3])))
 PY
-tail -3 gpurun_out/gantt.txt
+grep -A40 "^idle" gpurun_out/gantt.txt | head -60
 rm -rf gpurun_out/gt

@@ -10,7 +10,7 @@ python3 - "$f" <<'PY'
 import sqlite3, sys, collections
 c = sqlite3.connect(sys.argv[1])
 rows = c.execute("select name, start, end from kernels order by start").fetchall()
-idx = [i for i, r in enumerate(rows) if "k_witness_gather" in r[0]]
+idx = [i for i, r in enumerate(rows) if "k_gather_rows32" in r[0]]
 seg = rows[idx[-1]:] if idx else rows[len(rows) * 2 // 3:]
 tot = collections.defaultdict(lambda: [0, 0])
 for nm, s, e in seg:
