@@ -583,14 +583,19 @@ int32_t jfhip_g1_sum_partials(int32_t curve_id, const void* d_partials, size_t c
 
 // Independent MSMs of a batch, fanned out over up to MAX_LANES streams that fork from / join into st->s.
 // `stage` (optional) uploads the scalars of entry b on the lane's stream and returns their device pointer.
+// `srs_of` (optional): entry b commits against its own SRS handle (the levels of a multilinear parameter) instead of srs.
 static int32_t msm_batch_locked(const jfhip_srs* srs, const size_t* lens, size_t batch, uint8_t* d_res, size_t rec,
                                 jfhip_stream* st,
-                                const std::function<int32_t(size_t, jfhip_stream*, const void**)>& stage) {
-    size_t maxlen = 0;
-    for (size_t b = 0; b < batch; b++) maxlen = lens[b] > maxlen ? lens[b] : maxlen;
+                                const std::function<int32_t(size_t, jfhip_stream*, const void**)>& stage,
+                                const std::function<const jfhip_srs*(size_t)>& srs_of = nullptr) {
+    size_t maxwork = 0;
+    for (size_t b = 0; b < batch; b++) {
+        const size_t w = lens[b] * (size_t)(srs_of ? srs_of(b) : srs)->W;
+        maxwork = w > maxwork ? w : maxwork;
+    }
     // lanes only pay off while the tails are a visible fraction of an MSM; each lane holds a workspace
     int lanes = 1;
-    if (batch > 1 && maxlen * (size_t)srs->W <= ((size_t)1 << 26)) lanes = batch < 3 ? (int)batch : 3;
+    if (batch > 1 && maxwork <= ((size_t)1 << 26)) lanes = batch < 3 ? (int)batch : 3;
     if (lanes > 1) {
         if (!st->fork_ev) JF_HIP(hipEventCreateWithFlags(&st->fork_ev, hipEventDisableTiming));
         for (int i = 0; i < lanes - 1; i++) {
@@ -614,7 +619,7 @@ static int32_t msm_batch_locked(const jfhip_srs* srs, const size_t* lens, size_t
         jfhip_stream* ls = (b % lanes == 0) ? st : st->lane[b % lanes - 1];
         const void* d_scalars = nullptr;
         rc = stage(b, ls, &d_scalars);
-        if (rc == JFHIP_OK) rc = msm_device_locked(srs, 0, d_scalars, lens[b], d_res + b * rec, ls);
+        if (rc == JFHIP_OK) rc = msm_device_locked(srs_of ? srs_of(b) : srs, 0, d_scalars, lens[b], d_res + b * rec, ls);
     }
     // join the lanes whatever happened: the caller may release its buffers as soon as this returns an error, and
     // the lanes may still be reading / writing them
@@ -892,21 +897,36 @@ int32_t jfhip_mle_open(const jfhip_srs* const* levels, size_t nv, const uint64_t
     const size_t rec = (pt + 4 + 15) & ~(size_t)15;
     JF_TRY(st->poly_a.ensure(n * 32));          // f
     JF_TRY(st->poly_b.ensure(n * 16 + 32));      // r (next f), ping-pong with f
-    JF_TRY(st->poly_c.ensure(n * 16 + 32));      // q
+    JF_TRY(st->poly_c.ensure(n * 32));           // q of every round, back to back (n - 1 values in all)
     JF_TRY(st->quot_consts.ensure(nv * 32));
     JF_TRY(st->ntt_io.ensure(nv * rec));
     JF_HIP(hipMemcpyAsync(st->poly_a.p, evals, n * 32, hipMemcpyHostToDevice, st->s));
     JF_HIP(hipMemcpyAsync(st->quot_consts.p, point, nv * 32, hipMemcpyHostToDevice, st->s));
     uint32_t* f = st->poly_a.as<uint32_t>();
     uint32_t* r = st->poly_b.as<uint32_t>();
+    // all folds first (round i + 1 needs only r of round i), every q kept; then the nv commitments as one batch: the
+    // short MSMs of the late rounds are latency-bound and overlap on the library's lane streams
+    std::vector<size_t> lens(nv), q_at(nv);
+    size_t at = 0;
     for (size_t i = 0; i < nv; i++) {
         const size_t half = (size_t)1 << (nv - 1 - i);
-        JF_TRY(mle_fold_device(curve, f, half, st->quot_consts.as<uint32_t>() + i * 8, st->poly_c.as<uint32_t>(), r, st));
-        JF_TRY(msm_device_locked(levels[i], 0, st->poly_c.p, half, st->ntt_io.as<uint8_t>() + i * rec, st));
+        lens[i] = half;
+        q_at[i] = at;
+        JF_TRY(mle_fold_device(curve, f, half, st->quot_consts.as<uint32_t>() + i * 8,
+                               st->poly_c.as<uint32_t>() + at * 8, r, st));
+        at += half;
         uint32_t* t = f;
         f = r;
         r = t;
     }
+    const uint8_t* q_base = st->poly_c.as<uint8_t>();
+    JF_TRY(msm_batch_locked(
+        levels[0], lens.data(), nv, st->ntt_io.as<uint8_t>(), rec, st,
+        [&](size_t b, jfhip_stream*, const void** d) {
+            *d = q_base + q_at[b] * 32;
+            return (int32_t)JFHIP_OK;
+        },
+        [&](size_t b) { return levels[b]; }));
     std::vector<uint8_t> host(nv * rec);
     JF_HIP(hipMemcpyAsync(host.data(), st->ntt_io.p, nv * rec, hipMemcpyDeviceToHost, st->s));
     JF_HIP(hipMemcpyAsync(out_eval, f, 32, hipMemcpyDeviceToHost, st->s));   // the table folded to one value: f(point)
