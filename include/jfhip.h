@@ -387,8 +387,8 @@ int32_t jfhip_witness_gather_device(const void *d_witness, size_t num_vars, cons
 int32_t jfhip_field_op(int32_t field_id, int32_t op, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n);
 
 /* op: 0 out = P + Q (packed affine, host), 1 out = k * P (k: Fr Montgomery, passed as Q);
- *     2, 3: the same two through the MSM tail's group law on lazily reduced 29-bit limbs (csrc/msm.hip p29_add,
- *     p29_double): same results. */
+ *     2, 3: the same two through the MSM tail's group law on lazily reduced 29-bit limbs (csrc/g29.hpp p29_add,
+ *     p29_double), 4: k * P by the group-element DFT's non-adjacent-form multiplication (p29_mul_scalar): same results. */
 int32_t jfhip_g1_op(int32_t curve_id, int32_t op, const uint64_t *P, const uint64_t *Q, uint64_t *out);
 
 /* Host-only: the Keccak-f[1600] permutation on 25 little-endian u64 lanes, in place.  Used by the host side of the

@@ -442,6 +442,7 @@ int32_t jfhip_srs_gen_for_testing(int32_t curve_id, const uint64_t* beta_mont, c
 int32_t jfhip_srs_free(jfhip_srs* srs) {
     if (!srs) return JFHIP_OK;
     for (jfhip_srs* p : srs->prefixes) (void)jfhip_srs_free(p);
+    for (auto& kv : srs->fk_dft) (void)hipFree(kv.second);
     if (srs->table) (void)hipFree(srs->table);
     delete srs;
     return JFHIP_OK;
@@ -1239,7 +1240,7 @@ int32_t jfhip_field_op(int32_t field_id, int32_t op, const uint64_t* a, const ui
 
 int32_t jfhip_g1_op(int32_t curve_id, int32_t op, const uint64_t* P, const uint64_t* Q, uint64_t* out) {
     JF_TRY(check_curve(curve_id));
-    if (!P || !Q || !out || op < 0 || op > 3) {
+    if (!P || !Q || !out || op < 0 || op > 4) {
         set_error("bad argument");
         return JFHIP_ERR_INVALID;
     }

@@ -166,6 +166,9 @@ struct jfhip_srs {
     // much shorter than the SRS (api.hip srs_route): the handle's own table would make it clear and fold 2^(c-1) buckets
     mutable std::mutex prefix_mu;
     mutable std::vector<jfhip_srs*> prefixes;
+    // FK23 (ecntt.hip): the group-element DFT of the first d points, zero-extended to 2^log_M, depends on the SRS only;
+    // kept per (d, log_M) after the first multi-open of that shape (2^log_M saturated XYZZ elements), under prefix_mu
+    mutable std::map<std::pair<uint32_t, uint32_t>, uint32_t*> fk_dft;
 };
 
 namespace jf {

@@ -15,28 +15,11 @@
 #include "common.hpp"
 #include "curve.hpp"
 #include "fp29.hpp"
+#include "g29.hpp"
 
 namespace jf {
 
 constexpr int EC_BLOCK = 64;
-
-// k * P, k a canonical (non-Montgomery) integer of Fr::N limbs
-template <class Cv>
-JF_DEV XYZZ<Cv> xyzz_mul_scalar(const XYZZ<Cv>& P, const Fp<typename Cv::Fr>& k) {
-    constexpr int N = Cv::Fr::N;
-    XYZZ<Cv> r = XYZZ<Cv>::identity();
-    int top = -1;
-    for (int i = N - 1; i >= 0 && top < 0; i--)
-        if (k.v[i]) top = 32 * i + 31 - __clz(k.v[i]);
-    for (int bit = top; bit >= 0; bit--) {
-        r = xyzz_double<Cv>(r);
-        uint32_t word = 0;
-#pragma unroll
-        for (int i = 0; i < N; i++) word = (i == (bit >> 5)) ? k.v[i] : word;
-        if ((word >> (bit & 31)) & 1u) xyzz_add<Cv>(r, P);
-    }
-    return r;
-}
 
 // tw[j] = w_M^(+-j) as a canonical integer, j < M / 2; (lo, hi, a): two-level table of w_M (ntt_root_tables)
 template <class Cv>
@@ -97,15 +80,21 @@ __global__ __launch_bounds__(EC_BLOCK) void k_ec_layer(uint32_t* __restrict__ da
     const uint32_t half = 1u << (s - 1);
     const uint32_t j = t & (half - 1), grp = t >> (s - 1);
     const uint32_t i0 = (grp << s) + j, i1 = i0 + half;
-    XYZZ<Cv> a = xyzz_load<Cv>(data + (size_t)i0 * XZ);
-    XYZZ<Cv> b = xyzz_load<Cv>(data + (size_t)i1 * XZ);
-    if (j && !b.is_inf()) b = xyzz_mul_scalar<Cv>(b, fp_load<Fr>(tw + (size_t)(j << (log_M - s)) * Fr::N));
-    XYZZ<Cv> sum = a;
-    xyzz_add<Cv>(sum, b);
-    b.Y = fp_neg<Q>(b.Y);
-    xyzz_add<Cv>(a, b);
-    xyzz_store<Cv>(data + (size_t)i0 * XZ, sum);
-    xyzz_store<Cv>(data + (size_t)i1 * XZ, a);
+    // in memory the elements stay saturated XYZZ; the butterfly runs on the 29-bit-limb group law (g29.hpp)
+    P29<Cv> a = p29_from_std<Cv>(xyzz_load<Cv>(data + (size_t)i0 * XZ));
+    P29<Cv> b = p29_from_std<Cv>(xyzz_load<Cv>(data + (size_t)i1 * XZ));
+    P29<Cv> nb;
+    if (j && !b.inf) {
+        b = p29_mul_scalar<Cv>(b, fp_load<Fr>(tw + (size_t)(j << (log_M - s)) * Fr::N));
+        nb = p29_neg<Cv, 2>(b);
+    } else {
+        nb = p29_neg<Cv, 1>(b);
+    }
+    P29<Cv> sum = a;
+    p29_add<Cv>(sum, b);
+    p29_add<Cv>(a, nb);
+    xyzz_store<Cv>(data + (size_t)i0 * XZ, xyzz29_to_std<Cv>(sum.v, sum.inf));
+    xyzz_store<Cv>(data + (size_t)i1 * XZ, xyzz29_to_std<Cv>(a.v, a.inf));
 }
 
 // data[k] = (scalars[k] * extra) . data[k]   (scalars, extra: Fr Montgomery)
@@ -119,7 +108,8 @@ __global__ __launch_bounds__(EC_BLOCK) void k_ec_scale(uint32_t* __restrict__ da
     XYZZ<Cv> p = xyzz_load<Cv>(data + (size_t)k * XZ);
     if (p.is_inf()) return;
     const Fp<Fr> sc = fp_from_mont<Fr>(fp_mul<Fr>(fp_load<Fr>(scalars + (size_t)k * Fr::N), fp_load<Fr>(extra)));
-    xyzz_store<Cv>(data + (size_t)k * XZ, xyzz_mul_scalar<Cv>(p, sc));
+    const P29<Cv> r = p29_mul_scalar<Cv>(p29_from_std<Cv>(p), sc);
+    xyzz_store<Cv>(data + (size_t)k * XZ, xyzz29_to_std<Cv>(r.v, r.inf));
 }
 
 // r_m = f_{d - m}, m <= d, zero up to M  (f: d + 1 coefficients)
@@ -206,9 +196,31 @@ static int32_t multi_open_rou_t(const jfhip_srs* srs, const uint32_t* d_coeffs, 
     uint32_t* P = pts.b.as<uint32_t>();
     uint32_t* T = tmp.b.as<uint32_t>();
     hipLaunchKernelGGL((k_ec_minv<Cv>), dim3(1), dim3(64), 0, st->s, log_M, par.b.as<uint32_t>());
-    // DFT_M(S): S_k for k < d
-    hipLaunchKernelGGL((k_ec_from_srs<Cv>), dim3((M + 255) / 256), dim3(256), 0, st->s, srs->table, (int)srs->f29, d, M, P);
-    JF_TRY(ec_ntt_t<Cv>(srs->curve, P, T, tw.b.as<uint32_t>(), log_M, 0, st));
+    // DFT_M(S): S_k for k < d.  It depends on the SRS only: computed on the first multi-open of this shape, then copied
+    // from the handle (a third of the group transforms of a call)
+    {
+        std::lock_guard<std::mutex> lk(srs->prefix_mu);
+        const auto key = std::make_pair(d, log_M);
+        auto it = srs->fk_dft.find(key);
+        if (it == srs->fk_dft.end()) {
+            hipLaunchKernelGGL((k_ec_from_srs<Cv>), dim3((M + 255) / 256), dim3(256), 0, st->s, srs->table, (int)srs->f29, d,
+                               M, P);
+            JF_TRY(ec_ntt_t<Cv>(srs->curve, P, T, tw.b.as<uint32_t>(), log_M, 0, st));
+            uint32_t* keep = nullptr;
+            if (hipMalloc(&keep, (size_t)M * XZ * 4) == hipSuccess) {
+                // other host threads read it without any ordering on this stream: complete before it is published
+                if (hipMemcpyAsync(keep, P, (size_t)M * XZ * 4, hipMemcpyDeviceToDevice, st->s) == hipSuccess &&
+                    hipStreamSynchronize(st->s) == hipSuccess)
+                    srs->fk_dft[key] = keep;
+                else
+                    (void)hipFree(keep);
+            } else {
+                (void)hipGetLastError();   // no room to keep it: recomputed next time
+            }
+        } else {
+            JF_HIP(hipMemcpyAsync(P, it->second, (size_t)M * XZ * 4, hipMemcpyDeviceToDevice, st->s));
+        }
+    }
     // DFT_M(r), r_m = f_{d - m}
     hipLaunchKernelGGL((k_ec_rev_coeffs<Cv>), dim3((M + 255) / 256), dim3(256), 0, st->s, d_coeffs, d, M,
                        sc.b.as<uint32_t>());

@@ -20,6 +20,7 @@
 #include "common.hpp"
 #include "curve.hpp"
 #include "fp29.hpp"
+#include "g29.hpp"
 
 namespace jf {
 
@@ -611,24 +612,6 @@ __global__ __launch_bounds__(128) void k_msm_accumulate(const uint32_t* __restri
 // limit of f29_mul, whose outputs are < 1.66 p):  X < 7.66, Y < 3.66, ZZ, ZZZ < 1.66;  P = U2 - X + 8p < 9.66,
 // R = S2 - Y + 4p < 5.66, X3 = R^2 - PPP - 2Q + 6p < 7.66, Q - X3 + 8p < 9.66, Y3 = .. - Y PPP + 2p < 3.66.
 template <class Cv>
-struct XYZZ29 {
-    using F = F29<typename Cv::Fq>;
-    F X, Y, ZZ, ZZZ;
-};
-
-template <class Cv>
-JF_DEV XYZZ<Cv> xyzz29_to_std(const XYZZ29<Cv>& a, bool inf) {
-    using Q = typename Cv::Fq;
-    if (inf) return XYZZ<Cv>::identity();
-    XYZZ<Cv> r;
-    r.X = f29_to_fp<Q>(a.X);
-    r.Y = f29_to_fp<Q>(a.Y);
-    r.ZZ = f29_to_fp<Q>(a.ZZ);
-    r.ZZZ = f29_to_fp<Q>(a.ZZZ);
-    return r;
-}
-
-template <class Cv>
 JF_DEV void xyzz29_store_raw(uint32_t* __restrict__ dst, const XYZZ29<Cv>& a, bool inf) {
     constexpr int L = F29<typename Cv::Fq>::L;
     static_assert((4 * L) % 4 == 0, "");
@@ -881,88 +864,6 @@ int32_t table_rescale(int32_t curve, uint32_t* d_pts, size_t count, int up, hipS
 // Y < 3.66 p, ZZ, ZZZ < 1.66 p; all zero = identity).  The fix-up, the fold and the sum tree add them as they are: a full
 // XYZZ addition on the 29-bit multiplier is ~3 300 instructions against ~5 200 saturated, and no element is converted
 // before the one result of the MSM.
-template <class Cv>
-struct P29 {
-    XYZZ29<Cv> v;
-    bool inf;
-};
-
-// cold: P + P, P - P (the general formulas divide by zero there), through the complete saturated addition
-template <class Cv>
-JF_COLD P29<Cv> p29_add_rare(P29<Cv> a, P29<Cv> b) {
-    using Q = typename Cv::Fq;
-    XYZZ<Cv> x = xyzz29_to_std<Cv>(a.v, a.inf), y = xyzz29_to_std<Cv>(b.v, b.inf);
-    xyzz_add<Cv>(x, y);
-    P29<Cv> r;
-    r.inf = x.is_inf();
-    r.v.X = f29_from_fp<Q>(x.X);
-    r.v.Y = f29_from_fp<Q>(x.Y);
-    r.v.ZZ = f29_from_fp<Q>(x.ZZ);
-    r.v.ZZZ = f29_from_fp<Q>(x.ZZZ);
-    return r;
-}
-
-// acc += q (add-2008-s on XYZZ).  Bounds in multiples of p, products < 1.1 p for factors within the invariants:
-// P, R = difference + 2p < 3.1; X3 = R^2 - PPP - 2Q + 6p < 7.1; Q - X3 + 8p < 9.1 (< 10.58, the contraction limit of
-// f29_mul for BN254); Y3 = R (Q - X3 + 8p) + (2p - S1) PPP in one reduction < 1.2; ZZ3, ZZZ3 < 1.1.
-template <class Cv>
-JF_DEV void p29_add(P29<Cv>& acc, const P29<Cv>& q) {
-    using Q = typename Cv::Fq;
-    using F = F29<Q>;
-    if (q.inf) return;
-    if (acc.inf) {
-        acc = q;
-        return;
-    }
-    F zero29;
-#pragma unroll
-    for (int i = 0; i < F::L; i++) zero29.v[i] = 0;
-    const F U1 = f29_mul<Q>(acc.v.X, q.v.ZZ);
-    const F U2 = f29_mul<Q>(q.v.X, acc.v.ZZ);
-    const F S1 = f29_mul<Q>(acc.v.Y, q.v.ZZZ);
-    const F S2 = f29_mul<Q>(q.v.Y, acc.v.ZZZ);
-    const F P = f29_sub<Q, 2>(U2, U1);
-    const F PP = f29_sqr<Q>(P);
-    if (f29_mulout_is_zero<Q>(PP)) {
-        acc = p29_add_rare<Cv>(acc, q);
-        return;
-    }
-    const F R = f29_sub<Q, 2>(S2, S1);
-    const F PPP = f29_mul<Q>(P, PP);
-    const F Qv = f29_mul<Q>(U1, PP);
-    const F X3 = f29_sub3<Q, 6>(f29_sqr<Q>(R), PPP, Qv, Qv);
-    const F Y3 = f29_dot2<Q>(R, f29_sub<Q, 8>(Qv, X3), f29_sub<Q, 2>(zero29, S1), PPP);
-    acc.v.ZZ = f29_mul<Q>(f29_mul<Q>(acc.v.ZZ, q.v.ZZ), PP);
-    acc.v.ZZZ = f29_mul<Q>(f29_mul<Q>(acc.v.ZZZ, q.v.ZZZ), PPP);
-    acc.v.X = X3;
-    acc.v.Y = Y3;
-}
-
-// 2 a (dbl-2008-s-1, curve coefficient a = 0).  U = 2Y < 7.4, V = U^2 < 1.4, W = U V, S = X V < 1.1, M = 3 X^2 < 4.1,
-// X3 = M^2 - 2S + 4p < 5.1, Y3 = M (S - X3 + 6p) + (2p - W) Y < 1.3.  No point of order two exists (odd group order).
-template <class Cv>
-JF_DEV P29<Cv> p29_double(const P29<Cv>& a) {
-    using Q = typename Cv::Fq;
-    using F = F29<Q>;
-    if (a.inf) return a;
-    F zero29;
-#pragma unroll
-    for (int i = 0; i < F::L; i++) zero29.v[i] = 0;
-    const F U = f29_normalize<Q>(f29_dbl_lazy<Q>(a.v.Y));
-    const F V = f29_sqr<Q>(U);
-    const F W = f29_mul<Q>(U, V);
-    const F S = f29_mul<Q>(a.v.X, V);
-    const F X2 = f29_sqr<Q>(a.v.X);
-    const F M = f29_normalize<Q>(f29_add_lazy<Q>(X2, f29_dbl_lazy<Q>(X2)));
-    P29<Cv> r;
-    r.inf = false;
-    r.v.X = f29_sub3<Q, 4>(f29_sqr<Q>(M), S, S, zero29);
-    r.v.Y = f29_dot2<Q>(M, f29_sub<Q, 6>(S, r.v.X), f29_sub<Q, 2>(zero29, W), a.v.Y);
-    r.v.ZZ = f29_mul<Q>(V, a.v.ZZ);
-    r.v.ZZZ = f29_mul<Q>(W, a.v.ZZZ);
-    return r;
-}
-
 // the two representations behind one interface: RAW = false saturated XYZZ (4 N words), RAW = true the above (4 L words)
 template <class Cv, bool RAW>
 struct Rep;
@@ -1461,22 +1362,16 @@ __global__ void k_g1_op(int op, const uint32_t* __restrict__ P, const uint32_t* 
     if (op == 0) {
         Affine<Cv> q = affine_load<Cv>(Qp);
         xyzz_add_affine<Cv>(acc, q);
+    } else if (op == 4) {
+        // the group-element DFT's scalar multiplication (g29.hpp p29_mul_scalar: non-adjacent form on 29-bit limbs)
+        const P29<Cv> r = p29_mul_scalar<Cv>(p29_from_std<Cv>(acc), fp_from_mont<Fr>(fp_load<Fr>(Qp)));
+        acc = xyzz29_to_std<Cv>(r.v, r.inf);
     } else if (op == 2 || op == 3) {
         // the MSM tail's group law on lazily reduced 29-bit limbs (p29_add / p29_double), same results as ops 0 / 1:
         // op 3's 256-step double-and-add chain feeds every output back in, which is what the stated bounds must survive
-        using Q = typename Cv::Fq;
-        auto lift = [](const XYZZ<Cv>& x) {
-            P29<Cv> r;
-            r.inf = x.is_inf();
-            r.v.X = f29_from_fp<Q>(x.X);
-            r.v.Y = f29_from_fp<Q>(x.Y);
-            r.v.ZZ = f29_from_fp<Q>(x.ZZ);
-            r.v.ZZZ = f29_from_fp<Q>(x.ZZZ);
-            return r;
-        };
-        P29<Cv> a = lift(acc);
+        P29<Cv> a = p29_from_std<Cv>(acc);
         if (op == 2) {
-            P29<Cv> b = lift(xyzz_from_affine<Cv>(affine_load<Cv>(Qp)));
+            P29<Cv> b = p29_from_std<Cv>(xyzz_from_affine<Cv>(affine_load<Cv>(Qp)));
             p29_add<Cv>(a, b);
             acc = xyzz29_to_std<Cv>(a.v, a.inf);
         } else {

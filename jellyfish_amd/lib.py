@@ -487,10 +487,13 @@ def g1_add(curve: int, P, Q, limbs29: bool = False) -> np.ndarray:
     return out
 
 
-def g1_mul(curve: int, P, k_mont, limbs29: bool = False) -> np.ndarray:
+def g1_mul(curve: int, P, k_mont, limbs29=False) -> np.ndarray:
+    """k * P; limbs29: True = double-and-add on the 29-bit-limb group law, "naf" = the group-element DFT's non-adjacent-
+    form multiplication on the same arithmetic (same results)"""
     P, k = _u64(P), _u64(k_mont)
     out = np.zeros(2 * FQ_LIMBS64[curve], dtype=np.uint64)
-    _check(load_library().jfhip_g1_op(curve, 3 if limbs29 else 1, _p(P), _p(k), _p(out)))
+    op = 4 if limbs29 == "naf" else (3 if limbs29 else 1)
+    _check(load_library().jfhip_g1_op(curve, op, _p(P), _p(k), _p(out)))
     return out
 
 

@@ -86,12 +86,16 @@ def test_group_ops_29bit_limbs(hip, cv):
         sm = mont_arr(cv.fr, [s])[0]
         got = hip.g1_mul(cid, G, sm, limbs29=True)
         assert (got == C.ec_mul(cid, G, sm)).all(), hex(s)
+        assert (hip.g1_mul(cid, G, sm, limbs29="naf") == got).all(), hex(s)
         pts.append(got)
     for a, b in zip(pts, pts[1:]):
         assert (hip.g1_add(cid, a, b, limbs29=True) == C.ec_add(cid, a, b)).all()
     # a chain on a random base point rather than the generator
     sm = mont_arr(cv.fr, [scal[-1]])[0]
     assert (hip.g1_mul(cid, pts[-2], sm, limbs29=True) == C.ec_mul(cid, pts[-2], sm)).all()
+    assert (hip.g1_mul(cid, pts[-2], sm, limbs29="naf") == C.ec_mul(cid, pts[-2], sm)).all()
+    zero = mont_arr(cv.fr, [0])[0]
+    assert pt_from(cv, hip.g1_mul(cid, G, zero, limbs29="naf")) is None
 
 
 @pytest.mark.parametrize("fname", list(FIELD_ID))

@@ -36,6 +36,21 @@ def test_multi_open_rou_equals_per_point_open(hip, cv, n, log_dom, num_points):
     srs.free()
 
 
+@pytest.mark.parametrize("cv", CURVES, ids=lambda c: c.name)
+def test_multi_open_rou_reuses_the_srs_transform(hip, cv):
+    """The group DFT of the SRS prefix is kept on the handle after the first call of a shape (csrc/ecntt.hip): a second
+    polynomial of the same degree, a shorter one (another shape) and the first one again all match per-point openings."""
+    n, log_dom = 40, 6
+    srs = hip.Srs.gen_for_testing(cv.curve_id, mont_arr(cv.fr, [0xFC23])[0], pt_arr(cv, cv.g), n)
+    srs_host = srs.read(0, n)
+    polys = [rand_fr_mont(cv, n, 31), rand_fr_mont(cv, n, 32), rand_fr_mont(cv, 33, 33), rand_fr_mont(cv, n, 31)]
+    for coeffs in polys:
+        proofs, infs = hip.kzg_multi_open_rou(srs, coeffs, log_dom, 9)
+        assert (proofs == _per_point(cv, srs_host, coeffs, log_dom, 9)).all()
+        assert not infs.any()
+    srs.free()
+
+
 def test_multi_open_rou_edge_cases(hip):
     cv = R.BN254
     beta = mont_arr(cv.fr, [77])[0]
