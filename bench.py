@@ -410,7 +410,13 @@ def main():
     ap.add_argument("--ultra-log-n", type=int, default=22,
                     help="also run BASELINE config 5: batch_prove of UltraPlonk BLS12-381 circuits of 2^K gates, "
                          "one circuit per GPU (config 5 is K = 22; 0 skips it)")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="only the timed 2^log_n MSM steps and the roofline of their dominant kernel: under "
+                         "rocprofv3 --kernel-trace --stats every k_msm_accumulate launch is then one of the metric's size")
     args = ap.parse_args()
+    if args.headline_only:
+        args.no_ntt = args.no_prove = args.no_cpu_baseline = True
+        args.ultra_log_n = 0
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus))
@@ -622,6 +628,8 @@ def main():
         # device-resident scalars (kernels only) and host scalars (scalar upload + kernels + one point back, the
         # timed region of kzg_gpu.rs:58-83)
         try:
+            if args.headline_only:
+                raise RuntimeError("skipped (--headline-only)")
             n2 = (1 << 20) + 1
             srs2 = L.Srs.gen_for_testing(L.BN254, beta, BN254_G, n2)
             sc2_host = np.ascontiguousarray(scalars_host[:n2])
