@@ -187,7 +187,9 @@ int32_t jfhip_kzg_open(const jfhip_srs *srs, const uint64_t *coeffs_mont, size_t
  * a Toeplitz product over group elements, run as group-element DFTs (pcs/src/toeplitz.rs:43-66, pcs/src/poly.rs:
  * 140-155) on the device, followed by the group DFT over the domain.  coeffs_mont: n Fr coefficients (host).  A
  * polynomial whose h has more coefficients than the domain is JFHIP_ERR_INVALID with poly.rs:145-150's message.  The
- * evaluations f(w^j) (multi_open_rou_evals, :397-417) are jfhip_ntt of the coefficients. */
+ * evaluations f(w^j) (multi_open_rou_evals, :397-417) are jfhip_ntt of the coefficients.  The transform of the SRS prefix
+ * depends on the handle and the degree only: it is kept on the handle after the first call of a shape (at most eight
+ * shapes, 2^(log of the convolution length) XYZZ elements each) and freed with it. */
 int32_t jfhip_kzg_multi_open_rou(const jfhip_srs *srs, const uint64_t *coeffs_mont, size_t n, uint32_t log_domain,
                                  size_t num_points, void *out_proofs_xy, uint8_t *out_infinity, jfhip_stream *stream);
 

@@ -207,7 +207,9 @@ static int32_t multi_open_rou_t(const jfhip_srs* srs, const uint32_t* d_coeffs, 
                                M, P);
             JF_TRY(ec_ntt_t<Cv>(srs->curve, P, T, tw.b.as<uint32_t>(), log_M, 0, st));
             uint32_t* keep = nullptr;
-            if (hipMalloc(&keep, (size_t)M * XZ * 4) == hipSuccess) {
+            if (srs->fk_dft.size() >= 8) {
+                // a caller cycling through many degrees: the handle keeps the first eight shapes only
+            } else if (hipMalloc(&keep, (size_t)M * XZ * 4) == hipSuccess) {
                 // other host threads read it without any ordering on this stream: complete before it is published
                 if (hipMemcpyAsync(keep, P, (size_t)M * XZ * 4, hipMemcpyDeviceToDevice, st->s) == hipSuccess &&
                     hipStreamSynchronize(st->s) == hipSuccess)
