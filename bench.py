@@ -111,6 +111,9 @@ def prove_section(L, torch, dist, world, stream, beta):
                     "transforms and quotient replicated" % world,
         "ms": round(float(np.median(ts)), 3), "runs_ms": [round(t, 3) for t in ts],
         "excluded": "host transcript and RNG (challenges / blinding are inputs); witness upload",
+        "note": "round 1's kernel sequence, kept as a fixed reference point: every polynomial transformed on all 8n points "
+                "of the quotient coset.  plonk_prove (the real prover) evaluates the quotient on 6n points and skips "
+                "identically-zero polynomials, which is why it is faster than this section",
         "commitments_sha": hashlib.sha256(bytes(commits.cpu().numpy().tobytes())).hexdigest()[:16]}
     srs_p.free()
     del hp
