@@ -130,7 +130,9 @@ int32_t jfhip_srs_read(const jfhip_srs *srs, size_t offset, size_t n, void *out_
  * which the shim maps to G1Affine::zero() as :989-991 does.
  * n == 0 yields the identity (zero polynomial).  offset + n > srs length is
  * JFHIP_ERR_INVALID ("poly degree {} is larger than allowed {}", :100-106).
- * Synchronous with respect to the host: the result is valid on return. */
+ * Synchronous with respect to the host: the result is valid on return.  From 2^20 terms on the scalars are uploaded
+ * in 2 (4 from 2^22) ranges whose partial sums run while the next range is in flight (same result; environment
+ * JFHIP_MSM_UPLOAD_CHUNKS=1 keeps one upload). */
 int32_t jfhip_msm(const jfhip_srs *srs, size_t offset, const uint64_t *scalars_mont, size_t n, void *out_xy,
                   uint8_t *out_infinity, jfhip_stream *stream);
 

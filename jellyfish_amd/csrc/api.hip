@@ -585,10 +585,14 @@ int32_t jfhip_g1_sum_partials(int32_t curve_id, const void* d_partials, size_t c
 // Independent MSMs of a batch, fanned out over up to MAX_LANES streams that fork from / join into st->s.
 // `stage` (optional) uploads the scalars of entry b on the lane's stream and returns their device pointer.
 // `srs_of` (optional): entry b commits against its own SRS handle (the levels of a multilinear parameter) instead of srs.
+// `offsets` (optional): entry b is the partial sum over points [offsets[b], offsets[b] + lens[b]), written as one
+// saturated XYZZ element (rec bytes apart) instead of a normalised point: the chunks of one MSM whose scalars arrive
+// from the host (jfhip_msm).
 static int32_t msm_batch_locked(const jfhip_srs* srs, const size_t* lens, size_t batch, uint8_t* d_res, size_t rec,
                                 jfhip_stream* st,
                                 const std::function<int32_t(size_t, jfhip_stream*, const void**)>& stage,
-                                const std::function<const jfhip_srs*(size_t)>& srs_of = nullptr) {
+                                const std::function<const jfhip_srs*(size_t)>& srs_of = nullptr,
+                                const size_t* offsets = nullptr) {
     size_t maxwork = 0;
     for (size_t b = 0; b < batch; b++) {
         const size_t w = lens[b] * (size_t)(srs_of ? srs_of(b) : srs)->W;
@@ -620,7 +624,13 @@ static int32_t msm_batch_locked(const jfhip_srs* srs, const size_t* lens, size_t
         jfhip_stream* ls = (b % lanes == 0) ? st : st->lane[b % lanes - 1];
         const void* d_scalars = nullptr;
         rc = stage(b, ls, &d_scalars);
-        if (rc == JFHIP_OK) rc = msm_device_locked(srs_of ? srs_of(b) : srs, 0, d_scalars, lens[b], d_res + b * rec, ls);
+        if (rc != JFHIP_OK) break;
+        const jfhip_srs* sb = srs_of ? srs_of(b) : srs;
+        if (offsets)
+            rc = msm_partial_device(srs_route(sb, offsets[b] + lens[b], ls), offsets[b], (const uint32_t*)d_scalars, lens[b],
+                                    (uint32_t*)(d_res + b * rec), ls);
+        else
+            rc = msm_device_locked(sb, 0, d_scalars, lens[b], d_res + b * rec, ls);
     }
     // join the lanes whatever happened: the caller may release its buffers as soon as this returns an error, and
     // the lanes may still be reading / writing them
@@ -743,12 +753,50 @@ int32_t jfhip_msm(const jfhip_srs* srs, size_t offset, const uint64_t* scalars, 
     JF_STREAM(st, stream);
     std::lock_guard<std::mutex> lk(st->mu);
     const size_t pt = 2 * (size_t)fq_bytes(srs->curve);
-    JF_TRY(st->scalars.ensure((n ? n : 1) * 32));
-    JF_TRY(st->ntt_io.ensure(pt + 16));
-    if (n) JF_HIP(hipMemcpyAsync(st->scalars.p, scalars, n * 32, hipMemcpyHostToDevice, st->s));
-    JF_TRY(msm_device_locked(srs, offset, st->scalars.p, n, st->ntt_io.p, st));
+    // Host scalars: the upload (32 B per term over PCIe: 1.0 ms for 2^20 terms from pageable memory) is a large part of
+    // the call.  From 2^20 terms on the MSM runs as 2 (4 from 2^22 terms) partial sums over point ranges on the lane
+    // streams, so the upload of one range overlaps the kernels of the previous one; the partial sums are added and
+    // normalised once.  Measured (scripts/host_msm_bench.py, BN254): 2^20 terms 3.08 -> 2.94 ms, 2^22 10.9 -> 8.7,
+    // 2^24 39.1 -> 28.0; below 2^20 the duplicated tails cost more than the overlap gains.
+    // JFHIP_MSM_UPLOAD_CHUNKS=1 keeps the single upload.
+    static const int env_chunks = getenv("JFHIP_MSM_UPLOAD_CHUNKS") ? atoi(getenv("JFHIP_MSM_UPLOAD_CHUNKS")) : 0;
+    size_t chunks = n >= ((size_t)1 << 22) ? 4 : n >= ((size_t)1 << 20) ? 2 : 1;
+    if (env_chunks >= 1 && env_chunks <= 8) chunks = (size_t)env_chunks;
+    if (chunks > n) chunks = n ? n : 1;
+    const uint8_t* d_result = nullptr;
+    if (chunks > 1) {
+        const size_t xz = 2 * pt;
+        JF_TRY(st->ntt_io.ensure(chunks * xz + pt + 16));
+        uint8_t* d_part = st->ntt_io.as<uint8_t>();
+        std::vector<size_t> lens(chunks), offs(chunks);
+        const size_t per = (n + chunks - 1) / chunks;
+        for (size_t b = 0; b < chunks; b++) {
+            const size_t lo = b * per < n ? b * per : n, hi = (b + 1) * per < n ? (b + 1) * per : n;
+            offs[b] = offset + lo;
+            lens[b] = hi - lo;
+        }
+        JF_TRY(msm_batch_locked(
+            srs, lens.data(), chunks, d_part, xz, st,
+            [&](size_t b, jfhip_stream* ls, const void** out) -> int32_t {
+                JF_TRY(ls->scalars.ensure((per ? per : 1) * 32));
+                if (lens[b])
+                    JF_HIP(hipMemcpyAsync(ls->scalars.p, scalars + (offs[b] - offset) * 4, lens[b] * 32,
+                                          hipMemcpyHostToDevice, ls->s));
+                *out = ls->scalars.p;
+                return JFHIP_OK;
+            },
+            nullptr, offs.data()));
+        JF_TRY(g1_sum_to_affine(srs->curve, (const uint32_t*)d_part, chunks, (uint32_t*)(d_part + chunks * xz), st));
+        d_result = d_part + chunks * xz;
+    } else {
+        JF_TRY(st->scalars.ensure((n ? n : 1) * 32));
+        JF_TRY(st->ntt_io.ensure(pt + 16));
+        if (n) JF_HIP(hipMemcpyAsync(st->scalars.p, scalars, n * 32, hipMemcpyHostToDevice, st->s));
+        JF_TRY(msm_device_locked(srs, offset, st->scalars.p, n, st->ntt_io.p, st));
+        d_result = st->ntt_io.as<uint8_t>();
+    }
     uint8_t host[160];
-    JF_HIP(hipMemcpyAsync(host, st->ntt_io.p, pt + 4, hipMemcpyDeviceToHost, st->s));
+    JF_HIP(hipMemcpyAsync(host, d_result, pt + 4, hipMemcpyDeviceToHost, st->s));
     JF_HIP(hipStreamSynchronize(st->s));
     memcpy(out_xy, host, pt);
     uint32_t inf;
