@@ -3,10 +3,11 @@
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line.
 A "step" is one BN254 G1 MSM (the arithmetic of UnivariateKzgPCS::commit, reference
-pcs/src/univariate_kzg/mod.rs:90-125) over 2^24 points per GPU with the SRS and the scalars
-already resident in HBM.  At N > 1 the point range is partitioned over the ranks
-(N * 2^24 points in total, weak scaling) and the only exchange is an RCCL all_gather of one
-group element per GPU.
+pcs/src/univariate_kzg/mod.rs:90-125) over 2^24 points with the SRS and the scalars
+already resident in HBM.  At N > 1 the SAME 2^24-point MSM is partitioned over the ranks by point
+range (2^24 / N points per GPU, strong scaling, the same group element as at N = 1) and the only
+exchange is an RCCL all_gather of one group element per GPU; the weak-scaling
+figure (2^24 points per GPU) is kept as the extra key `weak_scaling`.
 
 Extra objects on the same line:
   roofline      dominant kernel (bucket accumulation), INT32 VALU multiply-add rate vs the
@@ -386,7 +387,7 @@ def launch_ranks(n_gpus: int) -> int:
 
     import torch
 
-    have = torch.cuda.device_count()          # counting devices does not initialise the runtime
+    have = torch.cuda.device_count()          # no HIP work is started in this process: the ranks are child processes
     rehearse = os.environ.get("JF_BENCH_REHEARSE") == "1"
     if have < n_gpus and not rehearse:
         print("bench.py: --gpus %d asked for but only %d GPU(s) are visible; refusing to print a line for fewer GPUs "
@@ -453,67 +454,96 @@ def main():
     L.load_library()
     L.init(local_rank if world > 1 else 0)
 
-    n = 1 << args.log_n
-    # SRS shard of this rank: [beta^(rank*n + i)] g, i < n   (gen_srs_for_testing shape)
+    n_total = 1 << args.log_n
+    # The metric's MSM has 2^log_n points IN TOTAL.  N > 1: the point range is partitioned over the ranks (north_star: "MSM
+    # point ranges are partitioned per GPU"), rank k holds the SRS shard [beta^i] g, i in shard_range(2^log_n, k, N), and
+    # the matching scalars: strong scaling, and the same group element as at N = 1 (result_sha must not depend on N).
+    lo, hi = jdist.shard_range(n_total, rank, world)
+    n = hi - lo
     beta = uniform_fr(1, 0x6A660001, BN254_R)[0]
-    g = BN254_G
-    if rank:
-        # g' = [beta^(rank*n)] g: fold the exponent with the device scalar multiplication
-        shift = beta
-        e = rank * n
-        acc = None
-        base = beta.copy()
+
+    def shifted_generator(e: int):
+        """[beta^e] g: the exponent folded with the device field / group operations"""
+        if e == 0:
+            return BN254_G
+        acc, base = None, beta.copy()
         while e:
             if e & 1:
                 acc = base.copy() if acc is None else L.field_op(0, "mul", acc, base)
             base = L.field_op(0, "mul", base, base)
             e >>= 1
-        g = L.g1_mul(0, g, acc)
+        return L.g1_mul(0, BN254_G, acc)
+
     t0 = time.time()
-    srs = L.Srs.gen_for_testing(0, beta, g, n)
+    srs = L.Srs.gen_for_testing(0, beta, shifted_generator(lo), n)
     srs_build_s = time.time() - t0
-    scalars_host = uniform_fr(n, 0xC0FFEE + rank, BN254_R)
+    # every rank draws the same 2^log_n scalars and keeps its range (N = 1: all of them)
+    scalars_all = uniform_fr(n_total, 0xC0FFEE, BN254_R)
+    scalars_host = np.ascontiguousarray(scalars_all[lo:hi])
+    del scalars_all
     scalars = torch.from_numpy(scalars_host.view(np.int64)).cuda()
     stream = L.Stream(wrap_raw=torch.cuda.current_stream().cuda_stream)
     engine = jdist.HipMsmEngine(L, srs, stream)
 
-    def step():
-        return jdist.sharded_msm(engine, scalars)
+    def timed_steps(step, warmup, steps):
+        res = None
+        for _ in range(warmup):
+            res = step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            res = step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            dt = max_over_ranks(torch, dist, dt)
+        return dt, res
 
-    for _ in range(args.warmup):
-        res = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        elapsed = max_over_ranks(torch, dist, elapsed)
+    elapsed, res = timed_steps(lambda: jdist.sharded_msm(engine, scalars), args.warmup, args.steps)
     result_bytes = bytes(res.cpu().numpy().tobytes())
 
     out = None
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        value = world * n * args.steps / elapsed / 1e6
+        value = n_total * args.steps / elapsed / 1e6
         out = {
-            "metric": "MSM throughput, BN254 G1, 2^%d points per GPU (UnivariateKzgPCS::commit arithmetic)" % args.log_n,
+            "metric": "MSM throughput, BN254 G1, 2^%d points (UnivariateKzgPCS::commit arithmetic)%s"
+                      % (args.log_n, "" if world == 1 else ", point range partitioned over %d GPUs" % world),
             "value": round(value, 3), "unit": "Mpts/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None,   # the total is 2^log_n points at every N
             "dtype": "u32 limbs (256-bit Montgomery, INT32 VALU)", "data": "synthetic",
-            "config": {"workload": "msm_bn254_g1_2^%d_per_gpu" % args.log_n, "curve": "bn254",
-                       "points_per_gpu": n, "total_points": world * n, "window_bits": srs.window_bits,
+            "config": {"workload": "msm_bn254_g1_2^%d" % args.log_n, "curve": "bn254",
+                       "points_per_gpu": n, "total_points": n_total, "window_bits": srs.window_bits,
                        "srs": "[beta^i]g generated on device (%.2f s incl. window-multiple table)" % srs_build_s,
                        "scalars": "uniform in [0,r), Montgomery form, resident in HBM",
-                       "sharding": "point ranges per rank + all_gather of one XYZZ element per GPU" if world > 1 else "single GPU"},
+                       "sharding": "point range [k 2^%d / N, (k + 1) 2^%d / N) on rank k + all_gather of one XYZZ element "
+                                   "per GPU; same group element as at N = 1" % (args.log_n, args.log_n)
+                                   if world > 1 else "single GPU"},
             "result_sha": __import__("hashlib").sha256(result_bytes).hexdigest()[:16],
         }
+
+    if world > 1 and not args.headline_only:
+        # the round-1/2 figure, kept as an extra key: 2^log_n points PER rank (weak scaling, N * 2^log_n points in total)
+        srs_w = L.Srs.gen_for_testing(0, beta, shifted_generator(rank * n_total), n_total)
+        sc_w = torch.from_numpy(uniform_fr(n_total, 0xC0FFEE + rank, BN254_R).view(np.int64)).cuda()
+        eng_w = jdist.HipMsmEngine(L, srs_w, stream)
+        k_w = max(2, min(args.steps, 5))
+        el_w, _ = timed_steps(lambda: jdist.sharded_msm(eng_w, sc_w), 1, k_w)
+        if rank == 0:
+            out["weak_scaling"] = {"points_per_gpu": n_total, "total_points": world * n_total, "steps": k_w,
+                                   "ms_per_step": round(el_w / k_w * 1e3, 4),
+                                   "value": round(world * n_total * k_w / el_w / 1e6, 3), "unit": "Mpts/s",
+                                   "window_bits": srs_w.window_bits}
+        srs_w.free()
+        del sc_w, eng_w
+        torch.cuda.empty_cache()
 
     # ---- roofline of the dominant kernel + secondary measurements: rank 0, N = 1 only ----------
     if rank == 0 and world == 1:
@@ -541,7 +571,7 @@ def main():
         if os.path.exists(pmc_path):
             try:
                 pmc = json.load(open(pmc_path))
-                if pmc.get("workload") == out["config"]["workload"]:
+                if pmc.get("workload") in (out["config"]["workload"], out["config"]["workload"] + "_per_gpu"):
                     traffic = pmc.get("k_msm_accumulate_hbm_bytes")
             except Exception:
                 traffic = None

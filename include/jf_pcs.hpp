@@ -5,6 +5,7 @@
 // Names, argument meaning and error behaviour follow the reference:
 //   PolynomialCommitmentScheme for UnivariateKzgPCS<E>     pcs/src/univariate_kzg/mod.rs:59-211
 //     commit / batch_commit / open / batch_open            :90-125 / :128-140 / :144-180 / :187-211
+//     multi_point_open                                     :416-468
 //     multi_open_rou_proofs (FK23)                         :328-395
 //   GPUCommittable<E>                                      pcs/src/univariate_kzg/mod.rs:659-965
 //     gpu_commit, gpu_commit_with_loaded_prover_param, gpu_batch_commit,
@@ -367,34 +368,73 @@ class UnivariateKzgPCS {
         return proofs;
     }
 
+    // UnivariatePCS::multi_point_open (:416-468): one proof for the openings at several points + the evaluations
+    static Result<std::pair<UnivariateKzgProof<E>, std::vector<Evaluation>>> multi_point_open(
+        DeviceSrs<E>& srs, const Polynomial& poly, const std::vector<Point>& points) {
+        if (points.empty()) return PCSError{PCSError::InvalidParameters, "no point to evaluate and open"};
+        constexpr size_t PT = 2 * E::FQ_LIMBS;
+        uint64_t xy[PT];
+        uint8_t inf = 0;
+        std::vector<Evaluation> evals(points.size());
+        int32_t rc = jfhip_kzg_multi_point_open(srs.get(), poly.coeffs.empty() ? nullptr : poly.coeffs[0].data(),
+                                                poly.coeffs.size(), points[0].data(), points.size(), xy, &inf,
+                                                evals[0].data(), nullptr);
+        if (rc) return last_error(rc);
+        return std::make_pair(UnivariateKzgProof<E>{to_affine(xy, inf)}, std::move(evals));
+    }
+
     // ===== the trait's own signatures: commit / batch_commit / open take the HOST prover parameters =====
     // (pcs/src/lib.rs:72-124: `fn commit(prover_param: impl Borrow<ProverParam>, poly)`.)  The reference uploads the SRS
     // inside every gpu_commit (:664-680); a drop-in that did so would pay the upload + window table per commitment, so
-    // the device copy is cached process-wide per powers_of_g allocation, keyed on (data pointer, length): the
-    // PlonkKzgSnark prover passes the same ProvingKey::commit_key to all of its ~13-18 commits per proof.  The key is an
-    // address: call evict_prover_param(pp) before freeing or mutating a UnivariateProverParam whose commits went
-    // through these overloads (a Rust wrapper does it in Drop).  At most SRS_CACHE_MAX entries, least recently used out.
+    // the device copy is cached process-wide per powers_of_g allocation: the PlonkKzgSnark prover passes the same
+    // ProvingKey::commit_key to all of its ~13-18 commits per proof.  The key is (data pointer, length) plus a
+    // FINGERPRINT of the contents (SURVEY.md 8b "Ownership": first / last / four sampled points): an allocation that is
+    // freed and whose address and length are then reused by different parameters hashes differently and is uploaded
+    // again instead of silently committing against the stale device copy.  evict_prover_param(pp) drops an entry at
+    // once (a Rust wrapper does it in Drop).  At most SRS_CACHE_MAX entries, least recently used out.
     static constexpr size_t SRS_CACHE_MAX = 4;
+    // FNV-1a over the bytes of up to six points: first, last and four evenly spaced ones
+    static uint64_t fingerprint(const UnivariateProverParam<E>& pp) {
+        const size_t n = pp.powers_of_g.size();
+        uint64_t h = 0xcbf29ce484222325ull;
+        auto mix = [&](const G1Affine<E>& p) {
+            const uint64_t inf = p.infinity ? 1 : 0;
+            const uint64_t* words[3] = {p.x.data(), p.y.data(), &inf};
+            const size_t counts[3] = {p.x.size(), p.y.size(), 1};
+            for (int k = 0; k < 3; k++)
+                for (size_t i = 0; i < counts[k]; i++)
+                    for (int b = 0; b < 8; b++) {
+                        h ^= (words[k][i] >> (8 * b)) & 0xff;
+                        h *= 0x100000001b3ull;
+                    }
+        };
+        for (size_t j = 0; j < 6 && j < n; j++) mix(pp.powers_of_g[n <= 6 ? j : j * (n - 1) / 5]);
+        return h;
+    }
     static Result<std::shared_ptr<DeviceSrs<E>>> cached_prover_param(const UnivariateProverParam<E>& pp) {
         if (pp.powers_of_g.empty()) return PCSError{PCSError::InvalidParameters, "empty prover parameters"};
         auto& c = cache();
         const Key key{pp.powers_of_g.data(), pp.powers_of_g.size()};
+        const uint64_t fp = fingerprint(pp);
         std::lock_guard<std::mutex> lk(c.mu);
         auto it = c.map.find(key);
         if (it != c.map.end()) {
-            it->second.second = ++c.clock;
-            return it->second.first;
+            if (it->second.fingerprint == fp) {
+                it->second.last_use = ++c.clock;
+                return it->second.srs;
+            }
+            c.map.erase(it);   // same address and length, other contents: the allocation was reused
         }
         auto srs = load_prover_param_to_gpu(pp, pp.powers_of_g.size() - 1);   // under the lock: one upload per key
         if (srs.is_err()) return srs.unwrap_err();
         if (c.map.size() >= SRS_CACHE_MAX) {
             auto victim = c.map.begin();
             for (auto j = c.map.begin(); j != c.map.end(); ++j)
-                if (j->second.second < victim->second.second) victim = j;
+                if (j->second.last_use < victim->second.last_use) victim = j;
             c.map.erase(victim);   // in-flight users keep their shared_ptr
         }
         auto sp = std::make_shared<DeviceSrs<E>>(std::move(srs.unwrap()));
-        c.map[key] = {sp, ++c.clock};
+        c.map[key] = CacheEntry{sp, fp, ++c.clock};
         return sp;
     }
     static void evict_prover_param(const UnivariateProverParam<E>& pp) {
@@ -430,11 +470,24 @@ class UnivariateKzgPCS {
         return open(*srs.unwrap(), poly, point);
     }
 
+    static Result<std::pair<UnivariateKzgProof<E>, std::vector<Evaluation>>> multi_point_open(
+        const UnivariateProverParam<E>& pp, const Polynomial& poly, const std::vector<Point>& points) {
+        if (points.empty()) return PCSError{PCSError::InvalidParameters, "no point to evaluate and open"};
+        auto srs = cached_prover_param(pp);
+        if (srs.is_err()) return srs.unwrap_err();
+        return multi_point_open(*srs.unwrap(), poly, points);
+    }
+
    private:
     using Key = std::pair<const void*, size_t>;
+    struct CacheEntry {
+        std::shared_ptr<DeviceSrs<E>> srs;
+        uint64_t fingerprint = 0;
+        uint64_t last_use = 0;
+    };
     struct Cache {
         std::mutex mu;
-        std::map<Key, std::pair<std::shared_ptr<DeviceSrs<E>>, uint64_t>> map;
+        std::map<Key, CacheEntry> map;
         uint64_t clock = 0;
     };
     static Cache& cache() {

@@ -145,8 +145,11 @@ int32_t jfhip_msm_batch(const jfhip_srs *srs, const uint64_t *const *scalars_mon
 
 /* batch_commit on DEVICE scalars (the prover keeps its polynomials in HBM): d_scalars is a HOST array
  * of `batch` device pointers; d_out receives `batch` records of ceil16(2*fq_bytes + 4) bytes, each a
- * packed affine point followed by a u32 infinity flag.  Asynchronous on `stream`; independent commits
- * run on internal auxiliary streams that fork from and join into `stream`. */
+ * packed affine point followed by a u32 infinity flag.  Asynchronous on `stream`.  The commits of a batch share ONE
+ * pipeline (the bucket id is widened by the polynomial index: one sort, one bucket accumulation, one fix-up / fold /
+ * sum tree and one normalisation launch for up to 16 polynomials), so the latency-bound tail of an MSM is paid once per
+ * batch; batches too large for that (more than 2^30 digit entries) run one after another on internal auxiliary streams
+ * that fork from and join into `stream`.  Environment JFHIP_MSM_FUSED=0 forces the latter (same results). */
 int32_t jfhip_msm_batch_device(const jfhip_srs *srs, const void *const *d_scalars_mont, const size_t *lens,
                                size_t batch, void *d_out, jfhip_stream *stream);
 
@@ -172,6 +175,12 @@ int32_t jfhip_msm_small(int32_t curve_id, const uint64_t *points_xy, const uint6
  * jfhip_g1_sum_partials on every rank. */
 int32_t jfhip_msm_partial_device(const jfhip_srs *srs, size_t offset, const void *d_scalars_mont, size_t n,
                                  void *d_out_xyzz, jfhip_stream *stream);
+/* The same for a batch_commit round (reference pcs/src/univariate_kzg/mod.rs:128-140 has no multi-device form): `batch`
+ * partial sums against one SRS, entry b over the points [offsets[b], offsets[b] + lens[b]) (offsets == NULL: all start
+ * at 0), written back to back as XYZZ elements in d_out_xyzz.  The entries share one sort / accumulate / fold pipeline
+ * like jfhip_msm_batch_device.  d_scalars_mont and offsets / lens are HOST arrays; asynchronous on `stream`. */
+int32_t jfhip_msm_batch_partial_device(const jfhip_srs *srs, const size_t *offsets, const void *const *d_scalars_mont,
+                                       const size_t *lens, size_t batch, void *d_out_xyzz, jfhip_stream *stream);
 /* Sum `count` XYZZ partials (device) and normalise: d_out as in jfhip_msm_device. */
 int32_t jfhip_g1_sum_partials(int32_t curve_id, const void *d_partials_xyzz, size_t count, void *d_out,
                               jfhip_stream *stream);
@@ -182,6 +191,16 @@ int32_t jfhip_g1_sum_partials(int32_t curve_id, const void *d_partials_xyzz, siz
  * n == 0: proof = identity, eval = 0. */
 int32_t jfhip_kzg_open(const jfhip_srs *srs, const uint64_t *coeffs_mont, size_t n, const uint64_t *point_mont,
                        void *out_proof_xy, uint8_t *out_infinity, uint64_t *out_eval_mont, jfhip_stream *stream);
+
+/* Replaces UnivariatePCS::multi_point_open (pcs/src/univariate_kzg/mod.rs:416-468): one proof for the openings of one
+ * polynomial at num_points points z_i (host, Montgomery, 4 limbs each): out_evals_mont[i] = f(z_i) (:433-436), and
+ * proof = commit(f / prod_i (X - z_i)), the polynomial quotient with the remainder discarded (:443-464), computed on the
+ * device as num_points successive synthetic divisions followed by one MSM.  num_points == 0 is JFHIP_ERR_INVALID with
+ * the reference's message "no point to evaluate and open" (:421-425).  n <= num_points (and n == 0): the quotient is
+ * zero, proof = identity.  num_points == 1 is jfhip_kzg_open.  The reference warns against many points (:415). */
+int32_t jfhip_kzg_multi_point_open(const jfhip_srs *srs, const uint64_t *coeffs_mont, size_t n,
+                                   const uint64_t *points_mont, size_t num_points, void *out_proof_xy,
+                                   uint8_t *out_infinity, uint64_t *out_evals_mont, jfhip_stream *stream);
 
 /* Replaces UnivariatePCS::multi_open_rou_proofs (pcs/src/univariate_kzg/mod.rs:328-395, FK23): the opening proofs
  * of one polynomial at the first num_points points w^j of the domain of 2^log_domain elements, proofs[j] =

@@ -646,6 +646,83 @@ static int32_t msm_batch_locked(const jfhip_srs* srs, const size_t* lens, size_t
     return rc;
 }
 
+// A batch against ONE SRS as fused pipelines of up to MSM_MAX_BATCH polynomials (msm.hip msm_multi_t): one sort, one
+// accumulation and one tail per pipeline instead of one per polynomial.  offsets == NULL: every polynomial starts at
+// point 0.  d_xyzz != NULL: the un-normalised partial sums (saturated XYZZ, back to back) instead of records in d_res.
+// Returns false (nothing enqueued) when the batch does not qualify and the caller should take the lane path.
+static bool msm_batch_fusable(const jfhip_srs* srs, const size_t* lens, size_t batch) {
+    static const bool on = [] {
+        const char* e = getenv("JFHIP_MSM_FUSED");
+        return !(e && e[0] == '0');
+    }();
+    if (!on || batch < 2) return false;
+    // the widened sort of a pipeline holds every polynomial's entries at once (20 B each): cap it at 2^30 entries
+    for (size_t b0 = 0; b0 < batch; b0 += MSM_MAX_BATCH) {
+        size_t terms = 0;
+        for (size_t b = b0; b < batch && b < b0 + MSM_MAX_BATCH; b++) terms += lens[b];
+        if (terms * (size_t)srs->W > ((size_t)1 << 30)) return false;
+    }
+    return true;
+}
+static int32_t msm_batch_fused_locked(const jfhip_srs* srs, const size_t* offsets, const void* const* d_scalars,
+                                      const size_t* lens, size_t batch, uint8_t* d_res, size_t rec, uint8_t* d_xyzz,
+                                      jfhip_stream* st) {
+    const size_t xz = 4 * (size_t)fq_bytes(srs->curve);
+    size_t end = 0;
+    for (size_t b = 0; b < batch; b++) {
+        const size_t e = (offsets ? offsets[b] : 0) + lens[b];
+        end = e > end ? e : end;
+    }
+    const jfhip_srs* table = srs_route(srs, end, st);
+    if (!d_xyzz) {
+        JF_TRY(st->result.ensure(batch * xz + 256));
+        d_xyzz = st->result.as<uint8_t>();
+    }
+    for (size_t b0 = 0; b0 < batch; b0 += MSM_MAX_BATCH) {
+        MsmBatch mb = {};
+        mb.count = (uint32_t)(batch - b0 < (size_t)MSM_MAX_BATCH ? batch - b0 : (size_t)MSM_MAX_BATCH);
+        for (uint32_t k = 0; k < mb.count; k++) {
+            mb.scalars[k] = (const uint32_t*)d_scalars[b0 + k];
+            mb.n[k] = (uint32_t)lens[b0 + k];
+            mb.offset[k] = (uint32_t)(offsets ? offsets[b0 + k] : 0);
+        }
+        JF_TRY(msm_multi_device(table, mb, (uint32_t*)(d_xyzz + b0 * xz), st));
+    }
+    if (d_res) JF_TRY(g1_batch_to_affine(srs->curve, (const uint32_t*)d_xyzz, batch, (uint32_t*)d_res, rec, st));
+    return JFHIP_OK;
+}
+
+int32_t jfhip_msm_batch_partial_device(const jfhip_srs* srs, const size_t* offsets, const void* const* d_scalars,
+                                       const size_t* lens, size_t batch, void* d_out_xyzz, jfhip_stream* stream) {
+    if (!srs) {
+        set_error("null SRS handle");
+        return JFHIP_ERR_INVALID;
+    }
+    if (batch == 0) return JFHIP_OK;
+    if (!d_scalars || !lens || !d_out_xyzz) {
+        set_error("null argument");
+        return JFHIP_ERR_INVALID;
+    }
+    for (size_t b = 0; b < batch; b++) {
+        JF_TRY(check_msm_range(srs, offsets ? offsets[b] : 0, lens[b]));
+        if (lens[b] && !d_scalars[b]) {
+            set_error("null scalar pointer for batch entry %zu", b);
+            return JFHIP_ERR_INVALID;
+        }
+    }
+    JF_STREAM(st, stream);
+    std::lock_guard<std::mutex> lk(st->mu);
+    const size_t xz = 4 * (size_t)fq_bytes(srs->curve);
+    if (msm_batch_fusable(srs, lens, batch))
+        return msm_batch_fused_locked(srs, offsets, d_scalars, lens, batch, nullptr, 0, (uint8_t*)d_out_xyzz, st);
+    for (size_t b = 0; b < batch; b++) {
+        const size_t off = offsets ? offsets[b] : 0;
+        JF_TRY(msm_partial_device(srs_route(srs, off + lens[b], st), off, (const uint32_t*)d_scalars[b], lens[b],
+                                  (uint32_t*)((uint8_t*)d_out_xyzz + b * xz), st));
+    }
+    return JFHIP_OK;
+}
+
 int32_t jfhip_msm_batch_device(const jfhip_srs* srs, const void* const* d_scalars, const size_t* lens, size_t batch,
                                void* d_out, jfhip_stream* stream) {
     if (!srs) {
@@ -667,6 +744,8 @@ int32_t jfhip_msm_batch_device(const jfhip_srs* srs, const void* const* d_scalar
     JF_STREAM(st, stream);
     std::lock_guard<std::mutex> lk(st->mu);
     const size_t rec = (2 * (size_t)fq_bytes(srs->curve) + 4 + 15) & ~(size_t)15;
+    if (msm_batch_fusable(srs, lens, batch))
+        return msm_batch_fused_locked(srs, nullptr, d_scalars, lens, batch, (uint8_t*)d_out, rec, nullptr, st);
     return msm_batch_locked(srs, lens, batch, (uint8_t*)d_out, rec, st,
                             [&](size_t b, jfhip_stream*, const void** out) -> int32_t {
                                 *out = d_scalars[b];
@@ -834,6 +913,68 @@ int32_t jfhip_kzg_open(const jfhip_srs* srs, const uint64_t* coeffs, size_t n, c
     uint8_t host[160];
     JF_HIP(hipMemcpyAsync(host, st->ntt_io.p, pt + 4, hipMemcpyDeviceToHost, st->s));
     JF_HIP(hipMemcpyAsync(out_eval, st->poly_c.p, 32, hipMemcpyDeviceToHost, st->s));
+    JF_HIP(hipStreamSynchronize(st->s));
+    memcpy(out_xy, host, pt);
+    uint32_t inf;
+    memcpy(&inf, host + pt, 4);
+    *out_inf = inf ? 1 : 0;
+    return JFHIP_OK;
+}
+
+// ---- multi_point_open (pcs/src/univariate_kzg/mod.rs:416-468) -----------------------------------------------------------
+// evals[i] = f(z_i); witness = f / prod_i (X - z_i) with the remainder discarded (ark's DensePolynomial division);
+// proof = commit(witness).  The quotient by the product is k successive synthetic divisions, each dropping its remainder:
+// floor(floor(f / A) / B) = floor(f / (A B)) for polynomials.  Everything on the device; k is small by the reference's own
+// warning ("don't use it when points.len() is large").
+int32_t jfhip_kzg_multi_point_open(const jfhip_srs* srs, const uint64_t* coeffs, size_t n, const uint64_t* points,
+                                   size_t num_points, void* out_xy, uint8_t* out_inf, uint64_t* out_evals,
+                                   jfhip_stream* stream) {
+    if (num_points == 0) {
+        set_error("no point to evaluate and open");   // mod.rs:421-425
+        return JFHIP_ERR_INVALID;
+    }
+    if (!srs || !points || !out_xy || !out_inf || !out_evals || (n && !coeffs)) {
+        set_error("null argument");
+        return JFHIP_ERR_INVALID;
+    }
+    const size_t pt = 2 * (size_t)fq_bytes(srs->curve);
+    const size_t k = num_points;
+    if (n == 0) {
+        memset(out_xy, 0, pt);
+        *out_inf = 1;
+        memset(out_evals, 0, k * 32);
+        return JFHIP_OK;
+    }
+    const size_t wlen = n > k ? n - k : 0;   // coefficients of the witness polynomial
+    JF_TRY(check_msm_range(srs, 0, wlen));
+    JF_STREAM(st, stream);
+    std::lock_guard<std::mutex> lk(st->mu);
+    JF_TRY(st->poly_a.ensure(n * 32));
+    JF_TRY(st->poly_c.ensure(n * 32));
+    JF_TRY(st->quot_consts.ensure(2 * k * 32));   // the points, then the evaluations
+    JF_TRY(st->ntt_io.ensure(pt + 16));
+    uint32_t* d_pts = st->quot_consts.as<uint32_t>();
+    uint32_t* d_evals = d_pts + k * 8;
+    JF_HIP(hipMemcpyAsync(d_pts, points, k * 32, hipMemcpyHostToDevice, st->s));
+    JF_HIP(hipMemcpyAsync(st->poly_a.p, coeffs, n * 32, hipMemcpyHostToDevice, st->s));
+    const uint32_t* d_f = st->poly_a.as<uint32_t>();
+    // polynomial.evaluate(point) for every point (:433-436)
+    for (size_t i = 0; i < k; i++)
+        JF_TRY(poly_eval_batch_device(srs->curve, &d_f, &n, 1, d_pts + i * 8, d_evals + i * 8, st));
+    // the division chain, ping-ponging between the two buffers: a step writes [remainder, quotient...]
+    const uint32_t* cur = d_f;
+    size_t len = n;
+    uint32_t* bufs[2] = {st->poly_c.as<uint32_t>(), st->poly_a.as<uint32_t>()};
+    for (size_t i = 0; i < k && len > 0; i++) {
+        uint32_t* dst = bufs[i & 1];
+        JF_TRY(open_witness_device(srs->curve, cur, len, d_pts + i * 8, dst, nullptr, st));
+        cur = dst + 8;
+        len -= 1;
+    }
+    JF_TRY(msm_device_locked(srs, 0, cur, len, st->ntt_io.p, st));
+    uint8_t host[160];
+    JF_HIP(hipMemcpyAsync(host, st->ntt_io.p, pt + 4, hipMemcpyDeviceToHost, st->s));
+    JF_HIP(hipMemcpyAsync(out_evals, d_evals, k * 32, hipMemcpyDeviceToHost, st->s));
     JF_HIP(hipStreamSynchronize(st->s));
     memcpy(out_xy, host, pt);
     uint32_t inf;

@@ -185,6 +185,20 @@ struct PhaseTimer {
     void finish();
 };
 
+// The MSMs of one pipeline (msm.hip msm_multi_t): polynomial p is n[p] scalars at scalars[p] against the points from
+// offset[p] on.  tile0 is filled by the pipeline (first sort tile of each polynomial).  Passed to kernels by value.
+constexpr int MSM_MAX_BATCH = 16;
+struct MsmBatch {
+    const uint32_t* scalars[MSM_MAX_BATCH];
+    uint32_t n[MSM_MAX_BATCH];
+    uint32_t offset[MSM_MAX_BATCH];
+    uint32_t tile0[MSM_MAX_BATCH + 1];
+    uint32_t count;
+};
+int32_t msm_multi_device(const jfhip_srs* srs, const MsmBatch& mb, uint32_t* d_out_xyzz, jfhip_stream* st);
+int32_t g1_batch_to_affine(int32_t curve, const uint32_t* d_xyzz, size_t count, uint32_t* d_out, size_t rec_bytes,
+                           jfhip_stream* st);
+
 // per-curve / per-field entry points implemented in msm.hip / ntt.hip / poly.hip
 int32_t msm_partial_device(const jfhip_srs* srs, size_t offset, const uint32_t* d_scalars, size_t n,
                            uint32_t* d_out_xyzz, jfhip_stream* st);

@@ -77,9 +77,19 @@ JF_DEV int32_t signed_digit(const uint32_t (&v)[N], int w, int c, uint32_t& carr
 
 // PASS = 0: coarse histogram only.  PASS = 1: reserve + scatter entries.  PASS = 2: per-tile histogram (for
 // k_msm_coarse_staged).
+// Which polynomial of a batch (MsmBatch, common.hpp) a sort tile belongs to: tiles are numbered polynomial by
+// polynomial, mb.tile0[p] is the first tile of polynomial p.  Uniform over the workgroup.
+JF_DEV uint32_t batch_entry_of_tile(const MsmBatch& mb, uint32_t tile) {
+    uint32_t p = 0;
+    for (uint32_t q = 1; q < mb.count; q++) p = (tile >= mb.tile0[q]) ? q : p;
+    return p;
+}
+
+// A batch shares one sort: the bucket id of polynomial p is widened to p * 2^(c-1) + bucket.  The coarse level gets that
+// for free -- a tile belongs to one polynomial, so its LDS histogram stays the 2^coarse_bits bins of ONE polynomial and
+// only the global bin id carries p.
 template <class Cv, int PASS>
-__global__ __launch_bounds__(256) void k_msm_coarse(const uint32_t* __restrict__ scalars, uint32_t n, DigitPlan pl,
-                                                    uint32_t tile_scalars, uint32_t table_n, uint32_t offset,
+__global__ __launch_bounds__(256) void k_msm_coarse(MsmBatch mb, DigitPlan pl, uint32_t tile_scalars, uint32_t table_n,
                                                     uint32_t* __restrict__ gcount /*PASS0: counts, PASS1: cursors*/,
                                                     uint2* __restrict__ entries) {
     using Fr = typename Cv::Fr;
@@ -88,7 +98,12 @@ __global__ __launch_bounds__(256) void k_msm_coarse(const uint32_t* __restrict__
     const uint32_t nb = 1u << pl.coarse_bits;
     for (uint32_t k = threadIdx.x; k < nb; k += 256) hist[k] = 0;
     __syncthreads();
-    const uint32_t tile0 = blockIdx.x * tile_scalars;
+    const uint32_t pe = batch_entry_of_tile(mb, blockIdx.x);
+    const uint32_t* __restrict__ scalars = mb.scalars[pe];
+    const uint32_t n = mb.n[pe], offset = mb.offset[pe];
+    const uint32_t ltile = blockIdx.x - mb.tile0[pe], ntiles = mb.tile0[pe + 1] - mb.tile0[pe];
+    const uint32_t pbase = pe << (pl.c - 1);   // this polynomial's first global bucket id
+    const uint32_t tile0 = ltile * tile_scalars;
     const int reps = (int)(tile_scalars / 256);
 
     for (int rep = 0; rep < reps; rep++) {
@@ -108,16 +123,17 @@ __global__ __launch_bounds__(256) void k_msm_coarse(const uint32_t* __restrict__
     __syncthreads();
     if (PASS == 0) {
         for (uint32_t k = threadIdx.x; k < nb; k += 256)
-            if (hist[k]) atomicAdd(&gcount[k], hist[k]);
+            if (hist[k]) atomicAdd(&gcount[pe * nb + k], hist[k]);
         return;
     }
-    if (PASS == 2) {   // histogram of this tile, [bin][tile] layout: its exclusive scan is every tile's offset in every bin
-        for (uint32_t k = threadIdx.x; k < nb; k += 256) gcount[(size_t)k * gridDim.x + blockIdx.x] = hist[k];
+    if (PASS == 2) {   // histogram of this tile, [polynomial][bin][tile] layout: its exclusive scan is every tile's offset in every bin
+        for (uint32_t k = threadIdx.x; k < nb; k += 256)
+            gcount[(size_t)nb * mb.tile0[pe] + (size_t)k * ntiles + ltile] = hist[k];
         return;
     }
     for (uint32_t k = threadIdx.x; k < nb; k += 256) {
         uint32_t h = hist[k];
-        base[k] = h ? atomicAdd(&gcount[k], h) : 0u;
+        base[k] = h ? atomicAdd(&gcount[pe * nb + k], h) : 0u;
         hist[k] = 0;
     }
     __syncthreads();
@@ -133,7 +149,7 @@ __global__ __launch_bounds__(256) void k_msm_coarse(const uint32_t* __restrict__
                     uint32_t cb = b >> pl.fine_bits;
                     uint32_t pos = base[cb] + atomicAdd(&hist[cb], 1u);
                     uint32_t payload = ((uint32_t)w * table_n + offset + i) | (d < 0 ? 0x80000000u : 0u);
-                    entries[pos] = make_uint2(payload, b);
+                    entries[pos] = make_uint2(payload, pbase | b);
                 }
             }
         }
@@ -323,19 +339,25 @@ JF_DEV uint32_t seg_search64(const uint32_t* __restrict__ segbase, uint32_t nseg
 
 // k_msm_coarse<Cv, 1> with staging: 256 scalars (<= STG_CAP entries, W <= 16) per flush, digits kept in registers
 template <class Cv>
-__global__ __launch_bounds__(256) void k_msm_coarse_staged(const uint32_t* __restrict__ scalars, uint32_t n, DigitPlan pl,
-                                                           uint32_t tile_scalars, uint32_t table_n, uint32_t offset,
-                                                           const uint32_t* __restrict__ tile_base /*[bin][tile]*/,
+__global__ __launch_bounds__(256) void k_msm_coarse_staged(MsmBatch mb, DigitPlan pl, uint32_t tile_scalars,
+                                                           uint32_t table_n,
+                                                           const uint32_t* __restrict__ tile_base /*[polynomial][bin][tile]*/,
                                                            uint2* __restrict__ entries) {
     using Fr = typename Cv::Fr;
     __shared__ uint2 stage[STG_CAP];
     __shared__ uint32_t cur[512], delta[512], tcur[512], wsum[4];
     const uint32_t nb = 1u << pl.coarse_bits;
-    // where this tile's entries of every bin go: exclusive scan of the [bin][tile] histogram (k_msm_coarse<Cv, 2>).  No
-    // atomics: with one global cursor per bin every flush of every workgroup queues on the same <= 512 addresses
-    // (measured ~80 ns per same-address atomic: 65536 flushes = 4.9 ms at 2^24).
-    for (uint32_t k = threadIdx.x; k < nb; k += 256) tcur[k] = tile_base[(size_t)k * gridDim.x + blockIdx.x];
-    const uint32_t tile0 = blockIdx.x * tile_scalars;
+    const uint32_t pe = batch_entry_of_tile(mb, blockIdx.x);
+    const uint32_t* __restrict__ scalars = mb.scalars[pe];
+    const uint32_t n = mb.n[pe], offset = mb.offset[pe];
+    const uint32_t ltile = blockIdx.x - mb.tile0[pe], ntiles = mb.tile0[pe + 1] - mb.tile0[pe];
+    const uint32_t pbase = pe << (pl.c - 1);
+    // where this tile's entries of every bin go: exclusive scan of the [polynomial][bin][tile] histogram
+    // (k_msm_coarse<Cv, 2>).  No atomics: with one global cursor per bin every flush of every workgroup queues on the same
+    // <= 512 addresses (measured ~80 ns per same-address atomic: 65536 flushes = 4.9 ms at 2^24).
+    for (uint32_t k = threadIdx.x; k < nb; k += 256)
+        tcur[k] = tile_base[(size_t)nb * mb.tile0[pe] + (size_t)k * ntiles + ltile];
+    const uint32_t tile0 = ltile * tile_scalars;
     const uint32_t tile1 = (tile0 + tile_scalars < n) ? tile0 + tile_scalars : n;
     for (uint32_t f0 = tile0; f0 < tile1; f0 += 256u) {
         const uint32_t i = f0 + threadIdx.x;
@@ -372,7 +394,7 @@ __global__ __launch_bounds__(256) void k_msm_coarse_staged(const uint32_t* __res
         __syncthreads();
         for (uint32_t e = threadIdx.x; e < m; e += 256) {
             const uint2 en = stage[e];
-            entries[delta[en.y >> pl.fine_bits] + e] = en;
+            entries[delta[en.y >> pl.fine_bits] + e] = make_uint2(en.x, pbase | en.y);
         }
         __syncthreads();
     }
@@ -503,14 +525,19 @@ __global__ __launch_bounds__(256) void k_scan_add(uint32_t* __restrict__ off, ui
     if (cursor) cursor[i] = v;
 }
 
-// coarse segment bases from the scanned [bin][tile] histogram: cbase[k] = scanned[k * tiles], cbase[nb] = total = off[B]
-__global__ __launch_bounds__(256) void k_msm_coarse_bases(const uint32_t* __restrict__ scanned, uint32_t nb, uint32_t tiles,
+// coarse segment bases from the scanned [polynomial][bin][tile] histogram: cbase[p * nb + k] = scanned[first tile of
+// (p, k)], cbase[count * nb] = total = off[B]  (scanned has one more entry than counters: the total)
+__global__ __launch_bounds__(256) void k_msm_coarse_bases(const uint32_t* __restrict__ scanned, uint32_t nb, MsmBatch mb,
                                                           uint32_t* __restrict__ cbase, uint32_t* __restrict__ off_total) {
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k > nb) return;
-    const uint32_t v = scanned[(size_t)k * tiles];
-    cbase[k] = v;
-    if (k == nb) *off_total = v;
+    const uint32_t kg = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t nbg = nb * mb.count;
+    if (kg > nbg) return;
+    const uint32_t pe = kg == nbg ? mb.count : kg / nb, k = kg == nbg ? 0u : kg % nb;
+    // an empty polynomial (no tiles) has no counters of its own: its bins start where the next polynomial's do
+    const uint32_t ntiles = kg == nbg ? 0u : mb.tile0[pe + 1] - mb.tile0[pe];
+    const uint32_t v = scanned[(size_t)nb * mb.tile0[pe] + (size_t)k * ntiles];
+    cbase[kg] = v;
+    if (kg == nbg) *off_total = v;
 }
 
 // Advance (b, b_lo, b_hi) to the bucket that holds sorted position `pos` (pos >= b_hi on entry).  The next bucket is
@@ -989,11 +1016,13 @@ JF_DEV typename Rep<Cv, RAW>::T rep_mul_small(const typename Rep<Cv, RAW>::T& p,
 
 // lane t folds buckets [t*g, (t+1)*g): V_t = sum_j (t*g + j + 1) * B[t*g + j].  A bucket that spans slices was summed
 // by the fix-up into `fixed`; every other one is where the accumulation left it (`acc_buckets`).
+// B counts the buckets of every polynomial of a batch (polynomial p owns [p * Bper, (p + 1) * Bper); g divides Bper, so a
+// lane never straddles two polynomials) and the weight of a bucket is its index inside its polynomial, plus one.
 template <class Cv, bool RAW>
 __global__ __launch_bounds__(64) void k_msm_bucket_fold(const uint32_t* __restrict__ fixed,
                                                         const uint32_t* __restrict__ acc_buckets,
-                                                        const uint32_t* __restrict__ off, uint32_t L, uint32_t B, uint32_t g,
-                                                        uint32_t* __restrict__ out) {
+                                                        const uint32_t* __restrict__ off, uint32_t L, uint32_t B,
+                                                        uint32_t Bper, uint32_t g, uint32_t* __restrict__ out) {
     using G = Rep<Cv, RAW>;
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if ((uint64_t)t * g >= B) return;
@@ -1006,8 +1035,9 @@ __global__ __launch_bounds__(64) void k_msm_bucket_fold(const uint32_t* __restri
         G::add(run, q);
         G::add(sum, run);
     }
-    if (lo) {
-        typename G::T sh = rep_mul_small<Cv, RAW>(run, lo);
+    const uint32_t lo_in = lo & (Bper - 1u);
+    if (lo_in) {
+        typename G::T sh = rep_mul_small<Cv, RAW>(run, lo_in);
         G::add(sum, sh);
     }
     G::store(out, t, sum);
@@ -1015,11 +1045,15 @@ __global__ __launch_bounds__(64) void k_msm_bucket_fold(const uint32_t* __restri
 
 // out[block] = sum of in[block*256*K ...): K serial loads per lane, then an LDS tree.  RAW: elements in the 29-bit form;
 // std_out: the block's sum is written as saturated XYZZ whatever the input form (the last launch of a tree)
+// blockIdx.y: independent sums of a batch, m elements each, laid out back to back (input segment y starts at element
+// y * m, its block sums at y * gridDim.x)
 template <class Cv, bool RAW>
 __global__ __launch_bounds__(256) void k_g1_sum(const uint32_t* __restrict__ in, uint32_t m, uint32_t per_lane, int std_out,
                                                 uint32_t* __restrict__ out) {
     using G = Rep<Cv, RAW>;
     __shared__ uint32_t sh[256 * G::W];
+    in += (size_t)blockIdx.y * m * G::W;
+    out += (size_t)blockIdx.y * gridDim.x * (std_out ? 4 * Cv::Fq::N : G::W);
     uint32_t base = blockIdx.x * 256u * per_lane;
     typename G::T acc = G::identity();
     for (uint32_t k = 0; k < per_lane; k++) {
@@ -1046,10 +1080,14 @@ __global__ __launch_bounds__(256) void k_g1_sum(const uint32_t* __restrict__ in,
 }
 
 // XYZZ -> packed affine + u32 infinity flag
+// one workgroup (its lane 0) per point: in_stride / out_stride in 32-bit words
 template <class Cv>
-__global__ void k_g1_to_affine(const uint32_t* __restrict__ in, uint32_t* __restrict__ out) {
+__global__ void k_g1_to_affine(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t in_stride,
+                               uint32_t out_stride) {
     constexpr int PT = 2 * Cv::Fq::N;
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (threadIdx.x != 0) return;
+    in += (size_t)blockIdx.x * in_stride;
+    out += (size_t)blockIdx.x * out_stride;
     XYZZ<Cv> p = xyzz_load<Cv>(in);
     Affine<Cv> a = xyzz_to_affine<Cv>(p);
     affine_store<Cv>(out, a);
@@ -1057,9 +1095,9 @@ __global__ void k_g1_to_affine(const uint32_t* __restrict__ in, uint32_t* __rest
 }
 
 template <class Cv>
-__global__ void k_g1_set_identity(uint32_t* __restrict__ out) {
+__global__ void k_g1_set_identity(uint32_t* __restrict__ out) {   // one saturated XYZZ element per workgroup of 64
     constexpr int XZ = 4 * Cv::Fq::N;
-    if (threadIdx.x < XZ && blockIdx.x == 0) out[threadIdx.x] = 0;
+    if (threadIdx.x < XZ) out[(size_t)blockIdx.x * XZ + threadIdx.x] = 0;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1516,13 +1554,14 @@ int32_t srs_gen_points(int32_t curve, const uint64_t* beta_mont, const uint64_t*
     return srs_gen_t<Bls381G1>(beta_mont, g_xy, n, d_out, st);
 }
 
-// tree of k_g1_sum launches, ping-ponging between red0 / red1; the final point -> d_out_xyzz, always saturated XYZZ.
-// RAW: d_in holds elements in the 29-bit form (Rep<Cv, true>)
+// tree of k_g1_sum launches, ping-ponging between red0 / red1; the final points -> d_out_xyzz, always saturated XYZZ.
+// RAW: d_in holds elements in the 29-bit form (Rep<Cv, true>).  segs independent sums of `count` elements each, back to
+// back in d_in; their results back to back in d_out_xyzz.
 template <class Cv, bool RAW>
-static int32_t g1_sum_xyzz_t(const uint32_t* d_in, size_t count, uint32_t* d_out_xyzz, jfhip_stream* st) {
+static int32_t g1_sum_xyzz_t(const uint32_t* d_in, size_t count, uint32_t* d_out_xyzz, jfhip_stream* st, size_t segs = 1) {
     constexpr int XW = Rep<Cv, RAW>::W;
     if (count == 0) {
-        hipLaunchKernelGGL((k_g1_set_identity<Cv>), dim3(1), dim3(64), 0, st->s, d_out_xyzz);
+        hipLaunchKernelGGL((k_g1_set_identity<Cv>), dim3((unsigned)segs), dim3(64), 0, st->s, d_out_xyzz);
         JF_HIP(hipGetLastError());
         return JFHIP_OK;
     }
@@ -1536,11 +1575,11 @@ static int32_t g1_sum_xyzz_t(const uint32_t* d_in, size_t count, uint32_t* d_out
         if (blocks == 1) dst = d_out_xyzz;
         else {
             DevBuf& buf = flip ? st->red1 : st->red0;
-            JF_TRY(buf.ensure(blocks * XW * 4));
+            JF_TRY(buf.ensure(segs * blocks * XW * 4));
             dst = buf.as<uint32_t>();
         }
-        hipLaunchKernelGGL((k_g1_sum<Cv, RAW>), dim3((unsigned)blocks), dim3(256), 0, st->s, cur, (uint32_t)m, per_lane,
-                           blocks == 1 ? 1 : 0, dst);
+        hipLaunchKernelGGL((k_g1_sum<Cv, RAW>), dim3((unsigned)blocks, (unsigned)segs), dim3(256), 0, st->s, cur,
+                           (uint32_t)m, per_lane, blocks == 1 ? 1 : 0, dst);
         JF_HIP(hipGetLastError());
         if (blocks == 1) break;
         cur = dst;
@@ -1550,24 +1589,39 @@ static int32_t g1_sum_xyzz_t(const uint32_t* d_in, size_t count, uint32_t* d_out
     return JFHIP_OK;
 }
 
+// The MSMs of a batch against one window table in ONE pipeline (UnivariateKzgPCS::batch_commit, reference
+// pcs/src/univariate_kzg/mod.rs:128-140; a single commit is the batch of one): the bucket id of polynomial p is widened
+// to p * 2^(c-1) + bucket, so one sort, one accumulation, one fix-up, one fold and one sum tree serve every polynomial
+// and the latency-bound tail (fix-up, fold, tree: ~0.45 ms of a 2^20-point MSM) is paid once per commit round instead of
+// once per polynomial.  d_out_xyzz: mb.count saturated XYZZ elements.
 template <class Cv>
-static int32_t msm_partial_t(const jfhip_srs* srs, size_t offset, const uint32_t* d_scalars, size_t n,
-                             uint32_t* d_out_xyzz, jfhip_stream* st) {
+static int32_t msm_multi_t(const jfhip_srs* srs, MsmBatch mb, uint32_t* d_out_xyzz, jfhip_stream* st) {
     constexpr int XZ = 4 * Cv::Fq::N;
     PhaseTimer pt(st, 0);
-    if (n == 0) {
-        hipLaunchKernelGGL((k_g1_set_identity<Cv>), dim3(1), dim3(64), 0, st->s, d_out_xyzz);
+    const uint32_t P = mb.count;
+    const int c = srs->c, W = srs->W;
+    const uint32_t Bper = 1u << (c - 1);
+    static const int env_tile = getenv("JFHIP_MSM_TILE") ? atoi(getenv("JFHIP_MSM_TILE")) : 0;
+    const uint32_t tile_scalars = env_tile >= 256 ? (uint32_t)(env_tile / 256 * 256) : (uint32_t)SORT_TILE_SCALARS;
+    size_t n_sum = 0;
+    mb.tile0[0] = 0;
+    for (uint32_t p = 0; p < P; p++) {
+        n_sum += mb.n[p];
+        mb.tile0[p + 1] = mb.tile0[p] + (uint32_t)((mb.n[p] + tile_scalars - 1) / tile_scalars);
+    }
+    if (n_sum == 0) {
+        hipLaunchKernelGGL((k_g1_set_identity<Cv>), dim3(P), dim3(64), 0, st->s, d_out_xyzz);
         JF_HIP(hipGetLastError());
         pt.finish();
         return JFHIP_OK;
     }
-    const int c = srs->c, W = srs->W;
-    const uint32_t B = 1u << (c - 1);
-    const size_t total_max = n * (size_t)W;
-    if (total_max >= ((size_t)1 << 32)) {
+    const size_t Bsz = (size_t)Bper * P;
+    const size_t total_max = n_sum * (size_t)W;
+    if (total_max >= ((size_t)1 << 32) || Bsz >= ((size_t)1 << 31)) {
         set_error("msm too large: n * windows = %zu exceeds 2^32", total_max);
         return JFHIP_ERR_INVALID;
     }
+    const uint32_t B = (uint32_t)Bsz;
     // slice length: one round of resident lanes (256 CUs x 4 SIMDs x 64 lanes x 4 waves of the saturated kernel, 3 of the
     // 29-bit one: a second, partly filled round runs at a fraction of the chip), at most 256 entries per lane
     static const int f29_occ = [] { const char* e = getenv("JFHIP_MSM_F29_OCC"); return e ? atoi(e) : 3; }();
@@ -1580,10 +1634,10 @@ static int32_t msm_partial_t(const jfhip_srs* srs, size_t offset, const uint32_t
     DigitPlan pl;
     pl.c = c;
     pl.W = W;
-    // bucket id bits are consumed in levels of <= 9 bits (staged scatters: runs of >= 16 entries per key and chunk)
+    // bucket id bits are consumed in levels of <= 9 bits (staged scatters: runs of >= 16 entries per key and chunk); the
+    // polynomial index of a batch rides on top of the coarse level's bin id and costs no level
     static const bool staged = !(getenv("JFHIP_MSM_SORT") && getenv("JFHIP_MSM_SORT")[0] == '0');
     static const int env_cb = getenv("JFHIP_MSM_COARSE_BITS") ? atoi(getenv("JFHIP_MSM_COARSE_BITS")) : -1;
-    static const int env_tile = getenv("JFHIP_MSM_TILE") ? atoi(getenv("JFHIP_MSM_TILE")) : 0;
     const int level_max = staged ? 9 : 8;
     if (staged) {
         const int nlev = (c - 1 + 8) / 9;
@@ -1601,22 +1655,25 @@ static int32_t msm_partial_t(const jfhip_srs* srs, size_t offset, const uint32_t
     }
     // a flush stages the <= 16 digits of 256 scalars; more windows than that (c < 16, small MSMs): direct scatter
     const bool staged_coarse = staged && W <= 16;
-    const uint32_t nb = 1u << pl.coarse_bits;
+    const uint32_t nb = 1u << pl.coarse_bits;    // coarse bins of one polynomial
+    const uint32_t nbg = nb * P;                 // ... of the batch
 
-    JF_TRY(st->dig.ensure(total_max * 8));     // level-1 entries (payload, fine bucket)
+    JF_TRY(st->dig.ensure(total_max * 8));     // level-1 entries (payload, bucket)
     JF_TRY(st->sorted.ensure(total_max * 4));
-    JF_TRY(st->counts.ensure(((size_t)nb + 1) * 4));
+    JF_TRY(st->counts.ensure(((size_t)nbg + 1) * 4));
     JF_TRY(st->offs.ensure(((size_t)B + 1) * 4));
-    JF_TRY(st->cursor.ensure(((size_t)nb + 1) * 4));
-    JF_TRY(st->bsum.ensure(((size_t)nb + 1) * 4));
+    JF_TRY(st->cursor.ensure(((size_t)nbg + 1) * 4));
+    JF_TRY(st->bsum.ensure(((size_t)nbg + 1) * 4));
     constexpr size_t XW = 4 * F29<typename Cv::Fq>::L;   // words of a raw (29-bit form) element, >= XZ
     JF_TRY(st->buckets.ensure((size_t)B * XW * 4));
     // fold: g buckets per lane, then a sum tree (the fold output reuses partA after the fix-up)
     // latency-bound for small bucket counts (few lanes, deep chains): short chains there
     static const int env_g = getenv("JFHIP_MSM_FOLD_G") ? atoi(getenv("JFHIP_MSM_FOLD_G")) : 0;
-    uint32_t g = (B <= (1u << 17)) ? 4 : (B <= (1u << 20)) ? 8 : 16;   // measured: BLS12-381 2^22 points (B = 2^19) 0.91 -> 0.73 ms with 8
-    if (env_g > 0) g = (uint32_t)env_g;
-    const uint32_t Tf = (B + g - 1) / g;
+    uint32_t g = (Bper <= (1u << 17)) ? 4 : (Bper <= (1u << 20)) ? 8 : 16;   // measured: BLS12-381 2^22 points (B = 2^19) 0.91 -> 0.73 ms with 8
+    if (env_g > 0 && (env_g & (env_g - 1)) == 0 && (uint32_t)env_g <= Bper) g = (uint32_t)env_g;
+    if (g > Bper) g = Bper;
+    const uint32_t Tf_per = Bper / g;            // fold outputs of one polynomial (g divides Bper: powers of two)
+    const size_t Tf = (size_t)Tf_per * P;
     JF_TRY(st->partA.ensure((T > Tf ? T : Tf) * XW * 4));
     JF_TRY(st->partB.ensure(T * XZ * 4));
 
@@ -1637,29 +1694,29 @@ static int32_t msm_partial_t(const jfhip_srs* srs, size_t offset, const uint32_t
         hipLaunchKernelGGL(k_scan_add, dim3((m + 255) / 256), dim3(256), 0, st->s, out_base, m, bs, out_cursor);
         return JFHIP_OK;
     };
-    const uint32_t tile_scalars = env_tile >= 256 ? (uint32_t)(env_tile / 256 * 256) : (uint32_t)SORT_TILE_SCALARS;
-    const unsigned tiles = (unsigned)((n + tile_scalars - 1) / tile_scalars);
+    const unsigned tiles = mb.tile0[P];
     if (staged_coarse) {
-        // per-tile histograms in [bin][tile] order; their exclusive scan places every tile in every coarse bin
+        // per-tile histograms in [polynomial][bin][tile] order; their exclusive scan places every tile in every coarse bin
         const size_t m = (size_t)nb * tiles;
         JF_TRY(st->tilehist.ensure((m + 1) * 4));
         JF_TRY(st->tilebase.ensure((m + 1) * 4));
-        hipLaunchKernelGGL((k_msm_coarse<Cv, 2>), dim3(tiles), dim3(256), 0, st->s, d_scalars, (uint32_t)n, pl,
-                           tile_scalars, (uint32_t)srs->n, (uint32_t)offset, st->tilehist.as<uint32_t>(), entries);
+        hipLaunchKernelGGL((k_msm_coarse<Cv, 2>), dim3(tiles), dim3(256), 0, st->s, mb, pl, tile_scalars,
+                           (uint32_t)srs->n, st->tilehist.as<uint32_t>(), entries);
         JF_TRY(scan(st->tilehist.as<uint32_t>(), (uint32_t)m, st->tilebase.as<uint32_t>(), (uint32_t*)nullptr));
-        hipLaunchKernelGGL(k_msm_coarse_bases, dim3((nb + 256) / 256), dim3(256), 0, st->s, st->tilebase.as<uint32_t>(), nb,
-                           tiles, cbase, offs + B);
+        hipLaunchKernelGGL(k_msm_coarse_bases, dim3((nbg + 256) / 256), dim3(256), 0, st->s, st->tilebase.as<uint32_t>(), nb,
+                           mb, cbase, offs + B);
         pt.mark();
-        hipLaunchKernelGGL((k_msm_coarse_staged<Cv>), dim3(tiles), dim3(256), 0, st->s, d_scalars, (uint32_t)n, pl,
-                           tile_scalars, (uint32_t)srs->n, (uint32_t)offset, st->tilebase.as<uint32_t>(), entries);
+        hipLaunchKernelGGL((k_msm_coarse_staged<Cv>), dim3(tiles), dim3(256), 0, st->s, mb, pl, tile_scalars,
+                           (uint32_t)srs->n, st->tilebase.as<uint32_t>(), entries);
     } else {
-        JF_HIP(hipMemsetAsync(counts, 0, ((size_t)nb + 1) * 4, st->s));
-        hipLaunchKernelGGL((k_msm_coarse<Cv, 0>), dim3(tiles), dim3(256), 0, st->s, d_scalars, (uint32_t)n, pl,
-                           tile_scalars, (uint32_t)srs->n, (uint32_t)offset, counts, entries);
-        hipLaunchKernelGGL(k_msm_coarse_scan, dim3(1), dim3(1024), 0, st->s, counts, nb, cbase, cursor, offs + B);
+        JF_HIP(hipMemsetAsync(counts, 0, ((size_t)nbg + 1) * 4, st->s));
+        hipLaunchKernelGGL((k_msm_coarse<Cv, 0>), dim3(tiles), dim3(256), 0, st->s, mb, pl, tile_scalars,
+                           (uint32_t)srs->n, counts, entries);
+        JF_TRY(scan(counts, nbg, cbase, cursor));
+        JF_HIP(hipMemcpyAsync(offs + B, cbase + nbg, 4, hipMemcpyDeviceToDevice, st->s));
         pt.mark();
-        hipLaunchKernelGGL((k_msm_coarse<Cv, 1>), dim3(tiles), dim3(256), 0, st->s, d_scalars, (uint32_t)n, pl,
-                           tile_scalars, (uint32_t)srs->n, (uint32_t)offset, cursor, entries);
+        hipLaunchKernelGGL((k_msm_coarse<Cv, 1>), dim3(tiles), dim3(256), 0, st->s, mb, pl, tile_scalars,
+                           (uint32_t)srs->n, cursor, entries);
     }
     {
         // refinement levels over the fine bits: one level if it fits, else two
@@ -1678,11 +1735,11 @@ static int32_t msm_partial_t(const jfhip_srs* srs, size_t offset, const uint32_t
         };
         const uint2* cur_entries = entries;
         const uint32_t* cur_base = cbase;
-        uint32_t cur_nseg = nb;
+        uint32_t cur_nseg = nbg;
         int rem = pl.fine_bits;
         if (rem > level_max) {
             const int lo_bits = rem / 2, hi_bits = rem - lo_bits;
-            const uint32_t nmid = nb << hi_bits;
+            const uint32_t nmid = nbg << hi_bits;
             JF_TRY(st->midbase.ensure(((size_t)nmid + 1) * 4));
             JF_TRY(st->midcnt.ensure(((size_t)nmid + 1) * 4));
             JF_TRY(st->midcur.ensure(((size_t)nmid + 1) * 4));
@@ -1731,8 +1788,8 @@ static int32_t msm_partial_t(const jfhip_srs* srs, size_t offset, const uint32_t
         hipLaunchKernelGGL((k_msm_fixup_heavy<Cv, true>), dim3(1024), dim3(256), 0, st->s, offs, (uint32_t)L, rawA, rawB,
                            buckets, st->heavy.as<uint32_t>());
         pt.mark();
-        hipLaunchKernelGGL((k_msm_bucket_fold<Cv, true>), dim3((Tf + 63) / 64), dim3(64), 0, st->s, buckets, raw, offs,
-                           (uint32_t)L, B, g, fold);
+        hipLaunchKernelGGL((k_msm_bucket_fold<Cv, true>), dim3((unsigned)((Tf + 63) / 64)), dim3(64), 0, st->s, buckets, raw,
+                           offs, (uint32_t)L, B, Bper, g, fold);
     } else {
         JF_HIP(hipMemsetAsync(buckets, 0, (size_t)B * XZ * 4, st->s));
         hipLaunchKernelGGL((k_msm_accumulate<Cv>), dim3((unsigned)((T + 127) / 128)), dim3(128), 0, st->s,
@@ -1745,22 +1802,39 @@ static int32_t msm_partial_t(const jfhip_srs* srs, size_t offset, const uint32_t
                            st->partA.as<uint32_t>(), st->partB.as<uint32_t>(), buckets, st->heavy.as<uint32_t>());
         pt.mark();
         // partA is free again after the fix-up
-        hipLaunchKernelGGL((k_msm_bucket_fold<Cv, false>), dim3((Tf + 63) / 64), dim3(64), 0, st->s, buckets, buckets, offs,
-                           (uint32_t)L, B, g, fold);
+        hipLaunchKernelGGL((k_msm_bucket_fold<Cv, false>), dim3((unsigned)((Tf + 63) / 64)), dim3(64), 0, st->s, buckets,
+                           buckets, offs, (uint32_t)L, B, Bper, g, fold);
     }
     JF_HIP(hipGetLastError());
     pt.mark();
-    if (srs->f29) JF_TRY((g1_sum_xyzz_t<Cv, true>(fold, Tf, d_out_xyzz, st)));
-    else JF_TRY((g1_sum_xyzz_t<Cv, false>(fold, Tf, d_out_xyzz, st)));
+    if (srs->f29) JF_TRY((g1_sum_xyzz_t<Cv, true>(fold, Tf_per, d_out_xyzz, st, P)));
+    else JF_TRY((g1_sum_xyzz_t<Cv, false>(fold, Tf_per, d_out_xyzz, st, P)));
     pt.mark();
     pt.finish();
     return JFHIP_OK;
 }
 
+int32_t msm_multi_device(const jfhip_srs* srs, const MsmBatch& mb, uint32_t* d_out_xyzz, jfhip_stream* st) {
+    if (mb.count == 0 || mb.count > MSM_MAX_BATCH) {
+        set_error("msm batch of %u polynomials (1..%d per pipeline)", mb.count, MSM_MAX_BATCH);
+        return JFHIP_ERR_INVALID;
+    }
+    if (srs->curve == JFHIP_BN254) return msm_multi_t<Bn254G1>(srs, mb, d_out_xyzz, st);
+    return msm_multi_t<Bls381G1>(srs, mb, d_out_xyzz, st);
+}
+
 int32_t msm_partial_device(const jfhip_srs* srs, size_t offset, const uint32_t* d_scalars, size_t n,
                            uint32_t* d_out_xyzz, jfhip_stream* st) {
-    if (srs->curve == JFHIP_BN254) return msm_partial_t<Bn254G1>(srs, offset, d_scalars, n, d_out_xyzz, st);
-    return msm_partial_t<Bls381G1>(srs, offset, d_scalars, n, d_out_xyzz, st);
+    MsmBatch mb = {};
+    mb.count = 1;
+    mb.scalars[0] = d_scalars;
+    mb.n[0] = (uint32_t)n;
+    mb.offset[0] = (uint32_t)offset;
+    if (n >= ((size_t)1 << 32)) {
+        set_error("msm too large: %zu terms", n);
+        return JFHIP_ERR_INVALID;
+    }
+    return msm_multi_device(srs, mb, d_out_xyzz, st);
 }
 
 template <class Cv>
@@ -1772,7 +1846,21 @@ static int32_t g1_sum_to_affine_t(const uint32_t* d_partials, size_t count, uint
         JF_TRY((g1_sum_xyzz_t<Cv, false>(d_partials, count, st->result.as<uint32_t>(), st)));
         src = st->result.as<uint32_t>();
     }
-    hipLaunchKernelGGL((k_g1_to_affine<Cv>), dim3(1), dim3(64), 0, st->s, src, d_out);
+    hipLaunchKernelGGL((k_g1_to_affine<Cv>), dim3(1), dim3(64), 0, st->s, src, d_out, 0u, 0u);
+    JF_HIP(hipGetLastError());
+    return JFHIP_OK;
+}
+
+// count saturated XYZZ elements (back to back) -> count records of rec_bytes (packed affine point + u32 infinity flag)
+int32_t g1_batch_to_affine(int32_t curve, const uint32_t* d_xyzz, size_t count, uint32_t* d_out, size_t rec_bytes,
+                           jfhip_stream* st) {
+    if (count == 0) return JFHIP_OK;
+    if (curve == JFHIP_BN254)
+        hipLaunchKernelGGL((k_g1_to_affine<Bn254G1>), dim3((unsigned)count), dim3(64), 0, st->s, d_xyzz, d_out,
+                           (uint32_t)(4 * Bn254G1::Fq::N), (uint32_t)(rec_bytes / 4));
+    else
+        hipLaunchKernelGGL((k_g1_to_affine<Bls381G1>), dim3((unsigned)count), dim3(64), 0, st->s, d_xyzz, d_out,
+                           (uint32_t)(4 * Bls381G1::Fq::N), (uint32_t)(rec_bytes / 4));
     JF_HIP(hipGetLastError());
     return JFHIP_OK;
 }

@@ -49,6 +49,15 @@ class HipMsmEngine:
         self.lib.msm_partial_device(self.srs, scalars.data_ptr(), n, out.data_ptr(), offset=offset, stream=self.stream)
         return out
 
+    def partial_batch(self, scalars: Sequence[torch.Tensor], offsets: Sequence[int]) -> torch.Tensor:
+        """the partial sums of a commit round in one shared pipeline (jfhip_msm_batch_partial_device)
+        -> uint8[len(scalars) * partial_bytes]"""
+        lens = [s.numel() * s.element_size() // 32 for s in scalars]
+        out = torch.empty(len(scalars) * self.partial_bytes, dtype=torch.uint8, device="cuda")
+        self.lib.msm_batch_partial_device(self.srs, [s.data_ptr() for s in scalars], lens, out.data_ptr(),
+                                          offsets=list(offsets), stream=self.stream)
+        return out
+
     def fold(self, partials: torch.Tensor, count: int) -> torch.Tensor:
         self.lib.g1_sum_partials(self.curve, partials.data_ptr(), count, self._out.data_ptr(), stream=self.stream)
         return self._out[: 2 * self.fq_bytes + 4]
@@ -98,12 +107,15 @@ def sharded_commit_batch(engine: MsmEngine, polys: Sequence[torch.Tensor], group
     P = len(polys)
     if P == 0:
         return []
-    parts = []
-    for poly in polys:
-        n = poly.numel() // 4
-        lo, hi = shard_range(n, rank, world)
-        parts.append(engine.partial(poly[4 * lo:4 * hi], offset=lo))
-    mine = torch.cat(parts)
+    ranges = [shard_range(poly.numel() // 4, rank, world) for poly in polys]
+    if hasattr(engine, "partial_batch"):
+        # the P partial sums of this rank in one sort / accumulate / fold pipeline
+        mine = engine.partial_batch([poly[4 * lo:4 * hi] for poly, (lo, hi) in zip(polys, ranges)],
+                                    [lo for lo, _ in ranges])
+        parts = [mine[j * engine.partial_bytes:(j + 1) * engine.partial_bytes] for j in range(P)]
+    else:
+        parts = [engine.partial(poly[4 * lo:4 * hi], offset=lo) for poly, (lo, hi) in zip(polys, ranges)]
+        mine = torch.cat(parts)
     if world == 1:
         return [engine.fold(parts[j], 1).clone() for j in range(P)]
     gathered = _all_gather_bytes(mine, world, group)

@@ -35,8 +35,8 @@ SYMBOLS = [
     "jfhip_stream_sync", "jfhip_stream_raw", "jfhip_stream_wrap", "jfhip_srs_load", "jfhip_srs_load_device",
     "jfhip_srs_load_serialized", "jfhip_msm_small",
     "jfhip_srs_gen_for_testing", "jfhip_srs_free", "jfhip_srs_len", "jfhip_srs_window_bits", "jfhip_srs_read",
-    "jfhip_msm", "jfhip_msm_batch", "jfhip_msm_batch_device", "jfhip_msm_device", "jfhip_msm_partial_device", "jfhip_g1_sum_partials",
-    "jfhip_kzg_open", "jfhip_kzg_multi_open_rou", "jfhip_mle_open", "jfhip_mle_fold_device", "jfhip_ntt", "jfhip_ntt_device", "jfhip_plonk_quotient_turbo_device", "jfhip_plonk_quotient_ultra_device", "jfhip_plonk_quotient_coset_device", "jfhip_plonk_quotient_masked_device", "jfhip_plonk_perm_product_device", "jfhip_plonk_lookup_product_device", "jfhip_plonk_lookup_merge_device", "jfhip_plonk_lookup_sorted_device", "jfhip_witness_gather_device", "jfhip_poly_divide_linear_device", "jfhip_poly_divide_linear_noalloc_device",
+    "jfhip_msm", "jfhip_msm_batch", "jfhip_msm_batch_device", "jfhip_msm_device", "jfhip_msm_partial_device", "jfhip_msm_batch_partial_device", "jfhip_g1_sum_partials",
+    "jfhip_kzg_open", "jfhip_kzg_multi_point_open", "jfhip_kzg_multi_open_rou", "jfhip_mle_open", "jfhip_mle_fold_device", "jfhip_ntt", "jfhip_ntt_device", "jfhip_plonk_quotient_turbo_device", "jfhip_plonk_quotient_ultra_device", "jfhip_plonk_quotient_coset_device", "jfhip_plonk_quotient_masked_device", "jfhip_plonk_perm_product_device", "jfhip_plonk_lookup_product_device", "jfhip_plonk_lookup_merge_device", "jfhip_plonk_lookup_sorted_device", "jfhip_witness_gather_device", "jfhip_poly_divide_linear_device", "jfhip_poly_divide_linear_noalloc_device",
     "jfhip_poly_lincomb_device", "jfhip_poly_eval_batch_device", "jfhip_field_op", "jfhip_g1_op", "jfhip_probe",
     "jfhip_set_profiling", "jfhip_last_phase_ms", "jfhip_phase_name", "jfhip_keccak_f1600",
 ]
@@ -265,6 +265,16 @@ def msm_partial_device(srs: Srs, d_scalars: int, n: int, d_out_xyzz: int, offset
                                                    _vp(d_out_xyzz), _sh(stream)))
 
 
+def msm_batch_partial_device(srs: Srs, d_scalars, lens, d_out_xyzz: int, offsets=None, stream: Stream | None = None):
+    """un-normalised partial sums of a batch_commit round (one shared pipeline): len(lens) XYZZ elements, back to back"""
+    batch = len(lens)
+    ptrs = (ctypes.c_void_p * max(batch, 1))(*[int(p) for p in d_scalars])
+    ls = (ctypes.c_size_t * max(batch, 1))(*[int(x) for x in lens])
+    offs = None if offsets is None else (ctypes.c_size_t * max(batch, 1))(*[int(x) for x in offsets])
+    _check(load_library().jfhip_msm_batch_partial_device(srs.h, offs, ptrs, ls, ctypes.c_size_t(batch), _vp(d_out_xyzz),
+                                                         _sh(stream)))
+
+
 def g1_sum_partials(curve: int, d_partials: int, count: int, d_out: int, stream: Stream | None = None):
     _check(load_library().jfhip_g1_sum_partials(curve, _vp(d_partials), ctypes.c_size_t(count), _vp(d_out),
                                                 _sh(stream)))
@@ -280,6 +290,19 @@ def kzg_open(srs: Srs, coeffs_mont, point_mont, stream: Stream | None = None):
     _check(load_library().jfhip_kzg_open(srs.h, _p(c) if n else None, ctypes.c_size_t(n), _p(z), _p(out),
                                          ctypes.byref(inf), _p(ev), _sh(stream)))
     return out, bool(inf.value), ev
+
+
+def kzg_multi_point_open(srs: Srs, coeffs_mont, points_mont, stream: Stream | None = None):
+    """UnivariatePCS::multi_point_open -> (proof packed affine, is_identity, evals (num_points, 4))"""
+    c, z = _u64(coeffs_mont), _u64(points_mont)
+    n, k = c.size // 4, z.size // 4
+    out = np.zeros(2 * FQ_LIMBS64[srs.curve], dtype=np.uint64)
+    ev = np.zeros((max(k, 1), 4), dtype=np.uint64)
+    inf = ctypes.c_uint8(0)
+    _check(load_library().jfhip_kzg_multi_point_open(srs.h, _p(c) if n else None, ctypes.c_size_t(n),
+                                                     _p(z) if k else None, ctypes.c_size_t(k), _p(out), ctypes.byref(inf),
+                                                     _p(ev), _sh(stream)))
+    return out, bool(inf.value), ev[:k]
 
 
 def plonk_lookup_sorted_device(d_table: int, n_table: int, d_lookups: int, n_lookups: int, d_sorted: int,

@@ -330,6 +330,52 @@ def commit_via_beta(cv: Curve, beta: int, g, coeffs):
     return ec_mul(cv, poly_eval(cv, coeffs, beta), g)
 
 
+def poly_mul(cv: Curve, a, b):
+    r = cv.fr.p
+    if not a or not b:
+        return []
+    out = [0] * (len(a) + len(b) - 1)
+    for i, x in enumerate(a):
+        for j, y in enumerate(b):
+            out[i + j] = (out[i + j] + x * y) % r
+    return out
+
+
+def poly_divide(cv: Curve, num, den):
+    """quotient of the naive long division ark-poly's `&DensePolynomial / &DensePolynomial` runs (remainder discarded);
+    den's leading coefficient must be non-zero"""
+    r = cv.fr.p
+    num = list(num)
+    while num and num[-1] % r == 0:
+        num.pop()
+    if len(num) < len(den):
+        return []
+    q = [0] * (len(num) - len(den) + 1)
+    lead_inv = pow(den[-1], -1, r)
+    rem = num
+    for k in range(len(q) - 1, -1, -1):
+        c = rem[k + len(den) - 1] * lead_inv % r
+        q[k] = c
+        if c:
+            for j, d in enumerate(den):
+                rem[k + j] = (rem[k + j] - c * d) % r
+    return q
+
+
+def multi_point_open_witness(cv: Curve, coeffs, points):
+    """UnivariatePCS::multi_point_open (pcs/src/univariate_kzg/mod.rs:416-468) up to the MSM: evaluations at every point
+    (:433-436), the divisor prod_i (X - z_i) folded left to right (:443-447), the witness polynomial = quotient of the
+    long division (:454).  -> (witness coefficients, evals)"""
+    if not points:
+        raise ValueError("no point to evaluate and open")   # :421-425
+    r = cv.fr.p
+    evals = [poly_eval(cv, coeffs, z) for z in points]
+    divisor = [(-points[0]) % r, 1]
+    for z in points[1:]:
+        divisor = poly_mul(cv, divisor, [(-z) % r, 1])
+    return poly_divide(cv, coeffs, divisor), evals
+
+
 def witness_poly(cv: Curve, coeffs, z: int):
     """(f(X) - f(z)) / (X - z): synthetic division; returns (quotient, remainder=f(z))."""
     r = cv.fr.p

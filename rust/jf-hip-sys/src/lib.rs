@@ -136,6 +136,15 @@ extern "C" {
         d_out_xyzz: *mut c_void,
         stream: *mut jfhip_stream,
     ) -> i32;
+    pub fn jfhip_msm_batch_partial_device(
+        srs: *const jfhip_srs,
+        offsets: *const usize,
+        d_scalars_mont: *const *const c_void,
+        lens: *const usize,
+        batch: usize,
+        d_out_xyzz: *mut c_void,
+        stream: *mut jfhip_stream,
+    ) -> i32;
     pub fn jfhip_g1_sum_partials(
         curve_id: i32,
         d_partials_xyzz: *const c_void,
@@ -151,6 +160,17 @@ extern "C" {
         out_proof_xy: *mut c_void,
         out_infinity: *mut u8,
         out_eval_mont: *mut u64,
+        stream: *mut jfhip_stream,
+    ) -> i32;
+    pub fn jfhip_kzg_multi_point_open(
+        srs: *const jfhip_srs,
+        coeffs_mont: *const u64,
+        n: usize,
+        points_mont: *const u64,
+        num_points: usize,
+        out_proof_xy: *mut c_void,
+        out_infinity: *mut u8,
+        out_evals_mont: *mut u64,
         stream: *mut jfhip_stream,
     ) -> i32;
     pub fn jfhip_kzg_multi_open_rou(

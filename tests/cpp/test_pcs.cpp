@@ -13,6 +13,7 @@ extern "C" {
 int jfo_srs_gen(int curve, const uint64_t* beta_mont, const uint64_t* g_xy, size_t n, uint64_t* out, int threads);
 int jfo_msm(int curve, const uint64_t* bases, const uint64_t* scalars_mont, size_t n, uint64_t* out_xy, int threads);
 int jfo_open_witness(int curve, const uint64_t* coeffs, size_t n, const uint64_t* z, uint64_t* q_out, uint64_t* eval_out);
+int jfo_poly_eval(int curve, const uint64_t* coeffs, size_t n, const uint64_t* z, uint64_t* out);
 int jfo_ntt(int curve, uint64_t* data, int log_n, size_t batch, int inverse, const uint64_t* coset_mont, int threads);
 int jfo_fp_unop(int field_id, int op, const uint64_t* a, uint64_t* out, size_t n);
 int jfo_fp_binop(int field_id, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
@@ -139,6 +140,54 @@ static void run(const uint64_t* g_xy) {
         PCS::evict_prover_param(half);
         PCS::evict_prover_param(pp);
         CHECK(PCS::cached_prover_params() == before);
+    }
+    // a freed SRS whose address and length are reused by DIFFERENT parameters must not commit against the stale device
+    // copy: the cache key carries a fingerprint of the contents (no evict call here, as after a plain drop + realloc)
+    {
+        UnivariateProverParam<E> reused;
+        reused.powers_of_g.assign(pp.powers_of_g.begin(), pp.powers_of_g.begin() + 1025);
+        DensePolynomial p = rand_poly(1000);
+        auto c1 = PCS::commit(reused, p);
+        CHECK(c1.is_ok() && c1.unwrap() == cpu_commit(p));
+        const size_t held = PCS::cached_prover_params();
+        // other parameters placed into the same buffer: [beta'^i] g with another beta
+        Fr beta2 = rand_fr();
+        std::vector<uint64_t> packed2(1025 * PT);
+        jfo_srs_gen(E::ID, beta2.data(), g_xy, 1025, packed2.data(), 8);
+        const void* addr = reused.powers_of_g.data();
+        for (size_t i = 0; i < 1025; i++) reused.powers_of_g[i] = from_packed<E>(&packed2[i * PT]);
+        CHECK(reused.powers_of_g.data() == addr);
+        auto c2 = PCS::commit(reused, p);
+        std::vector<uint64_t> out(PT);
+        jfo_msm(E::ID, packed2.data(), p.coeffs[0].data(), p.coeffs.size(), out.data(), 8);
+        CHECK(c2.is_ok() && c2.unwrap().point == from_packed<E>(out.data()));
+        CHECK(!(c2.unwrap() == c1.unwrap()));
+        CHECK(PCS::cached_prover_params() == held);   // the stale entry was replaced, not kept beside the new one
+        PCS::evict_prover_param(reused);
+    }
+    // multi_point_open (:416-468): k successive synthetic divisions on the oracle side
+    {
+        DensePolynomial p = rand_poly(600);
+        std::vector<Fr> pts{rand_fr(), rand_fr(), rand_fr()};
+        auto mo = PCS::multi_point_open(srs.unwrap(), p, pts);
+        CHECK(mo.is_ok() && mo.unwrap().second.size() == 3);
+        std::vector<Fr> cur = p.coeffs;
+        for (size_t i = 0; i < pts.size(); i++) {
+            Fr ev;
+            jfo_poly_eval(E::ID, p.coeffs[0].data(), p.coeffs.size(), pts[i].data(), ev.data());
+            CHECK(mo.unwrap().second[i] == ev);
+            std::vector<Fr> q(cur.size() - 1);
+            Fr rem;
+            jfo_open_witness(E::ID, cur[0].data(), cur.size(), pts[i].data(), q[0].data(), rem.data());
+            cur = q;
+        }
+        CHECK(mo.unwrap().first.proof == cpu_commit(DensePolynomial{cur}).point);
+        auto mo1 = PCS::multi_point_open(pp, p, {pts[0]});
+        auto o1 = PCS::open(srs.unwrap(), p, pts[0]);
+        CHECK(mo1.is_ok() && o1.is_ok() && mo1.unwrap().first.proof == o1.unwrap().first.proof);
+        auto bad = PCS::multi_point_open(srs.unwrap(), p, {});
+        CHECK(bad.is_err() && bad.unwrap_err().msg.find("no point to evaluate and open") != std::string::npos);
+        PCS::evict_prover_param(pp);
     }
     // empty batch -> Ok(vec![])
     CHECK(PCS::gpu_batch_commit(pp, {}).is_ok());

@@ -52,8 +52,33 @@ def test_rust_sys_crate_declares_every_symbol_with_the_same_arity():
     for f in ("Cargo.toml", "build.rs"):
         assert os.path.exists(os.path.join(ROOT, "rust", "jf-hip-sys", f))
     patch = open(os.path.join(ROOT, "rust", "patches", "jf-pcs-hip.patch")).read()
-    for sym in ("jfhip_srs_load", "jfhip_msm", "jfhip_msm_batch", "jfhip_kzg_open", "jfhip_last_error", "jfhip_srs_free"):
+    for sym in ("jfhip_srs_load", "jfhip_msm", "jfhip_msm_batch", "jfhip_kzg_open", "jfhip_kzg_multi_point_open",
+                "jfhip_last_error", "jfhip_srs_free", "jfhip_stream_create", "jfhip_stream_sync"):
         assert sym in patch and sym in c
+    # what INTEGRATION.md says the Rust side holds: the GPUCommittable method set (reference mod.rs:659-965) for both
+    # curves, the Drop hunk of srs.rs:40-44, the fingerprinted cache key
+    for text in ("pub trait GPUCommittable<E: Pairing>", "impl<E: HipCurve> GPUCommittable<E> for UnivariateKzgPCS<E>",
+                 "impl HipCurve for ark_bn254::Bn254", "impl HipCurve for ark_bls12_381::Bls12_381",
+                 "fn gpu_commit(", "fn gpu_commit_with_loaded_prover_param(", "fn gpu_batch_commit(",
+                 "fn gpu_batch_commit_with_loaded_prover_param(", "fn load_prover_param_to_gpu(", "fn load_poly_to_gpu",
+                 "fn load_batch_poly_to_gpu", "fn commit_on_gpu(", "fn load_commitments_to_host(",
+                 "impl<E: Pairing> Drop for UnivariateProverParam<E>", "fn fingerprint<E: Pairing>",
+                 "hip::multi_point_open::<E>"):
+        assert text in patch, text
+    # the NTT call-site patches go through rust/jf-hip, whose device call is jfhip_ntt
+    hip = open(os.path.join(ROOT, "rust", "jf-hip", "src", "lib.rs")).read()
+    assert "jfhip_ntt(" in hip and "jfhip_ntt" in c
+    for f in ("Cargo.toml",):
+        assert os.path.exists(os.path.join(ROOT, "rust", "jf-hip", f))
+    relation = open(os.path.join(ROOT, "rust", "patches", "jf-relation-hip.patch")).read()
+    plonk = open(os.path.join(ROOT, "rust", "patches", "jf-plonk-hip.patch")).read()
+    for text in ("jfhip_ntt", "jf_hip::ifft", "jf_hip::ifft_in_place"):
+        assert text in relation, text
+    # every iFFT site of the Arithmetization impl is swapped: 8 domain.ifft + 4 domain.ifft_in_place removed
+    assert relation.count("-") and sum(1 for ln in relation.splitlines() if ln.startswith("-") and "domain.ifft(" in ln) == 8
+    assert sum(1 for ln in relation.splitlines() if ln.startswith("-") and "domain.ifft_in_place(" in ln) == 4
+    for text in ("jfhip_ntt", "jf_hip::coset_fft_batch", "jf_hip::coset_ifft", 'hip = ["dep:jf-hip", "jf-pcs/hip", "jf-relation/hip"]'):
+        assert text in plonk, text
 
 
 def test_no_device_is_reported_not_crashed():

@@ -96,3 +96,41 @@ def test_poly_eval_batch(hip, lens):
     for i, p in enumerate(polys):
         assert (got[i] == C.poly_eval(0, p, z)).all(), lens[i]
     st.close()
+
+
+@pytest.mark.parametrize("cv", CURVES, ids=lambda c: c.name)
+def test_multi_point_open(hip, cv):
+    """UnivariatePCS::multi_point_open (pcs/src/univariate_kzg/mod.rs:416-468) through the C ABI against the restated
+    long division: several points, k = 1 (= open), repeated points, as many points as coefficients and more (zero
+    quotient), the empty polynomial, and the reference's error for no points."""
+    beta_i = 0x5EED1234
+    beta = mont_arr(cv.fr, [beta_i])[0]
+    n = 700
+    srs = hip.Srs.gen_for_testing(cv.curve_id, beta, pt_arr(cv, cv.g), n)
+    coeffs_m = rand_fr_mont(cv, n, 31)
+    coeffs = from_mont_arr(cv.fr, coeffs_m)
+    zs = from_mont_arr(cv.fr, rand_fr_mont(cv, 6, 32))
+    for pts in (zs[:4], zs[:1], [zs[0], zs[1], zs[0], zs[0]], zs[:6]):
+        proof, inf, ev = hip.kzg_multi_point_open(srs, coeffs_m, mont_arr(cv.fr, pts))
+        w, evals = R.multi_point_open_witness(cv, coeffs, pts)
+        assert from_mont_arr(cv.fr, ev) == evals
+        assert len(w) == n - len(pts)
+        assert pt_from(cv, proof) == R.commit_via_beta(cv, beta_i, cv.g, w) and not inf
+    # one point is open()
+    p1, _, e1 = hip.kzg_multi_point_open(srs, coeffs_m, mont_arr(cv.fr, zs[:1]))
+    p2, _, e2 = hip.kzg_open(srs, coeffs_m, mont_arr(cv.fr, zs[:1])[0])
+    assert (p1 == p2).all() and (e1[0] == e2).all()
+    # short polynomials: degree below the number of points -> zero witness, identity proof
+    for m in (3, 4, 5):
+        short = coeffs_m[:m]
+        proof, inf, ev = hip.kzg_multi_point_open(srs, short, mont_arr(cv.fr, zs[:4]))
+        w, evals = R.multi_point_open_witness(cv, coeffs[:m], zs[:4])
+        assert from_mont_arr(cv.fr, ev) == evals
+        assert pt_from(cv, proof) == (R.commit_via_beta(cv, beta_i, cv.g, w) if w else None)
+        assert inf == (not w)
+    proof, inf, ev = hip.kzg_multi_point_open(srs, np.zeros((0, 4), dtype=np.uint64), mont_arr(cv.fr, zs[:2]))
+    assert inf and not ev.any() and not proof.any()
+    with pytest.raises(hip.JfHipError) as e:
+        hip.kzg_multi_point_open(srs, coeffs_m, np.zeros((0, 4), dtype=np.uint64))
+    assert e.value.code == -1 and "no point to evaluate and open" in e.value.msg
+    srs.free()
