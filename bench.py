@@ -665,7 +665,10 @@ def main():
                 raise RuntimeError("skipped (--headline-only)")
             n2 = (1 << 20) + 1
             srs2 = L.Srs.gen_for_testing(L.BN254, beta, BN254_G, n2)
-            sc2_host = np.ascontiguousarray(scalars_host[:n2])
+            # its own 2^20 + 1 scalars when the headline ran on fewer (--log-n below 21): the device call reads n2 of them
+            sc2_host = (np.ascontiguousarray(scalars_host[:n2]) if scalars_host.shape[0] >= n2
+                        else uniform_fr(n2, 0xC0FFEE + 2, BN254_R))
+            assert sc2_host.shape == (n2, 4)
             sc2 = torch.from_numpy(sc2_host.view(np.int64)).cuda()
             o2 = torch.zeros(128, dtype=torch.uint8, device="cuda")
             t_dev, t_host = [], []
@@ -698,6 +701,7 @@ def main():
 
                 log_s = min(args.log_n, 24)
                 ns = 1 << log_s
+                assert scalars_host.shape[0] >= ns
                 bases = srs.read(0, ns)
                 threads = C.nthreads()
                 t0 = time.perf_counter()
@@ -712,7 +716,7 @@ def main():
                 if not args.no_prove:
                     # the prove path's two kernels on the same host cores: one 2^20-point MSM and one 2^23 coset NTT
                     # (BN254), extrapolated to config 4's 13 commitments + 26 size-8n + 7 size-n transforms
-                    n20 = 1 << 20
+                    n20 = min(1 << 20, ns)
                     t0 = time.perf_counter()
                     C.msm(0, bases[:n20], scalars_host[:n20], threads)
                     t_msm = time.perf_counter() - t0
@@ -807,4 +811,14 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException:
+        # a launcher (torch.distributed.run) reports only the exit status of a failed rank: say why, on stderr
+        import traceback
+
+        print("bench.py: rank %s failed:\n%s" % (os.environ.get("RANK", "0"), traceback.format_exc()), file=sys.stderr,
+              flush=True)
+        raise

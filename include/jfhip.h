@@ -55,7 +55,8 @@ int32_t jfhip_init(int32_t device);
 int32_t jfhip_shutdown(void);
 
 /* Free the process-wide caches of device tables (NTT twiddle tables per (domain size, direction, coset offset); the
- * quotient kernel's 1/(n(x_i - 1)) table per (n, m, offset), 32 B x m each) that no call in flight is using.  The caches
+ * quotient kernel's 1/(n(x_i - 1)) table per (n, m, offset), 32 B x m each) that no call in flight is using, and the
+ * FK23 transforms every live SRS handle keeps (jfhip_srs_release_caches).  The caches
  * are bounded anyway (least recently used first, JFHIP_CACHE_BYTES per cache, default 8 GiB); a long-running prover that
  * is done with a circuit size can give the memory back at once. */
 int32_t jfhip_cache_clear(void);
@@ -115,6 +116,11 @@ int32_t jfhip_srs_load_serialized(int32_t curve_id, const uint8_t *bytes, size_t
 int32_t jfhip_srs_gen_for_testing(int32_t curve_id, const uint64_t *beta_mont, const uint64_t *g_xy, size_t n,
                                   int32_t window_bits, jfhip_srs **out);
 int32_t jfhip_srs_free(jfhip_srs *srs);
+/* Give back the derived data a handle caches beyond its window tables -- the FK23 transforms of jfhip_kzg_multi_open_rou
+ * (at most JFHIP_FK_CACHE_BYTES per handle, default 4 GiB, least recently used out; a transform larger than the budget is
+ * never kept) -- without freeing the handle; they are rebuilt on demand.  jfhip_cache_clear() does this for every live
+ * handle.  No counterpart in the reference. */
+int32_t jfhip_srs_release_caches(jfhip_srs *srs);
 size_t jfhip_srs_len(const jfhip_srs *srs);
 int32_t jfhip_srs_window_bits(const jfhip_srs *srs);
 /* Copy packed affine points [offset, offset+n) of the SRS back to the host. */
@@ -371,9 +377,12 @@ int32_t jfhip_poly_divide_linear_device(int32_t curve_id, const void *d_coeffs, 
  * other allocating call, host or device.  Limits: n <= 2^23 coefficients (larger n: JFHIP_ERR_INVALID, use the call
  * above); `stream` must be a handle made at set-up (NULL is JFHIP_ERR_INVALID, because the per-thread default stream is
  * created on first use).  jfhip_init() on the device does the one-time set-up; without it the first call on a device
- * does.  All calls on one GPU share that GPU's array: calls that overlap on one GPU (different streams or threads) race
- * -- serialise them.  The array keeps the previous call's contents; the scan never reads an entry it has not written in
- * the same call, so nothing needs clearing.  Asynchronous on `stream`. */
+ * does.  The array used is that of the GPU `stream` belongs to (hipStreamGetDevice), whatever the calling thread's current
+ * device.  All calls on one GPU share that GPU's array: the library orders them (a per-device host mutex around the
+ * enqueue, and each call's stream waits on an event recorded after the previous call's last kernel -- no allocation
+ * either), except for streams under graph capture, whose callers must serialise calls that could overlap on one GPU.
+ * The array keeps the previous call's contents; the scan never reads an entry it has not written in the same call, so
+ * nothing needs clearing.  Asynchronous on `stream`. */
 int32_t jfhip_poly_divide_linear_noalloc_device(int32_t curve_id, const void *d_coeffs, size_t n,
                                                 const uint64_t *point_mont, void *d_out, jfhip_stream *stream);
 
@@ -423,6 +432,14 @@ int32_t jfhip_keccak_f1600(uint64_t *state25);
  * kind 0: v_mad_u64_u32 multiply-adds/s (INT32 VALU), kind 1: device copy bytes/s,
  * kind 2: Montgomery multiplications/s of the field given in `arg` (field_id). */
 int32_t jfhip_probe(int32_t kind, int32_t arg, double *out_rate);
+
+/* Device markers.  With the environment variable JFHIP_MARKERS=1 the library brackets its entry points with roctx ranges
+ * named after the reference's own timers ("Committing to polynomial of degree {}", "batch commit {} polynomials",
+ * "Opening polynomial of degree {}": pcs/src/univariate_kzg/mod.rs:96-123, 134, 158, 426-430; ark_std start_timer!), so a
+ * `rocprofv3 --kernel-trace --marker-trace` run segments by name.  These two let the host side add its own ranges (the
+ * prover's rounds) through the same roctx library; no-ops when markers are off or no roctx library is found. */
+int32_t jfhip_marker_push(const char *name);
+int32_t jfhip_marker_pop(void);
 
 /* Time (ms) the library's kernels of the last MSM / NTT call on this stream took on the
  * device, per phase, measured with HIP events on the stream the kernels ran on.

@@ -3,6 +3,8 @@
 // poly.hip; nothing here computes field or group operations on the host.
 #include <stdarg.h>
 
+#include <dlfcn.h>
+
 #include <functional>
 #include <thread>
 
@@ -39,6 +41,79 @@ size_t cache_byte_cap() {
         return v ? (size_t)v : (size_t)8 << 30;
     }();
     return cap;
+}
+
+// ---- device markers (roctx ranges) ---------------------------------------------------------------------------------
+// With JFHIP_MARKERS=1 the library brackets its entry points with roctx ranges named after the reference's own timers
+// (pcs/src/univariate_kzg/mod.rs:96-123 "Committing to polynomial of degree {}", :134 "batch commit {} polynomials",
+// :158 "Opening polynomial of degree {}", :426-430), so a `rocprofv3 --kernel-trace --marker-trace` run of a proof is
+// segmented by name instead of by kernel-name heuristics.  The roctx library is looked up at run time (rocprofv3's own,
+// then roctracer's); without it, or with the variable unset, the ranges are no-ops and nothing is loaded.
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+};
+static const Roctx& roctx() {
+    static const Roctx r = [] {
+        Roctx x;
+        const char* e = getenv("JFHIP_MARKERS");
+        if (!e || e[0] == '0') return x;
+        for (const char* lib : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4",
+                                "libroctx64.so"}) {
+            void* h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL);
+            if (!h) continue;
+            x.push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+            x.pop = (int (*)())dlsym(h, "roctxRangePop");
+            if (x.push && x.pop) return x;
+            x.push = nullptr;
+            x.pop = nullptr;
+        }
+        return x;
+    }();
+    return r;
+}
+struct MarkerRange {
+    bool on = false;
+    explicit MarkerRange(const char* fmt, ...) {
+        const Roctx& r = roctx();
+        if (!r.push) return;
+        char buf[160];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof(buf), fmt, ap);
+        va_end(ap);
+        r.push(buf);
+        on = true;
+    }
+    ~MarkerRange() {
+        if (on) roctx().pop();
+    }
+};
+
+size_t fk_cache_byte_cap() {
+    static const size_t cap = [] {
+        const char* e = getenv("JFHIP_FK_CACHE_BYTES");
+        unsigned long long v = e ? strtoull(e, nullptr, 10) : 0ull;
+        return e ? (size_t)v : (size_t)4 << 30;
+    }();
+    return cap;
+}
+
+// every live SRS handle, so that jfhip_cache_clear can reach the caches the handles own
+static std::mutex g_srs_mu;
+static std::vector<jfhip_srs*> g_srs_live;
+static void srs_register(jfhip_srs* s) {
+    std::lock_guard<std::mutex> lk(g_srs_mu);
+    g_srs_live.push_back(s);
+}
+static void srs_unregister(jfhip_srs* s) {
+    std::lock_guard<std::mutex> lk(g_srs_mu);
+    for (size_t i = 0; i < g_srs_live.size(); i++)
+        if (g_srs_live[i] == s) {
+            g_srs_live[i] = g_srs_live.back();
+            g_srs_live.pop_back();
+            break;
+        }
 }
 
 void set_error(const char* fmt, ...) {
@@ -189,6 +264,7 @@ static int32_t srs_alloc(int32_t curve, size_t n, int32_t window_bits, jfhip_srs
         delete s;
         return hip_fail(e, "hipMalloc(SRS table)", __FILE__, __LINE__);
     }
+    srs_register(s);
     *out = s;
     return JFHIP_OK;
 }
@@ -228,7 +304,9 @@ int32_t jfhip_init(int32_t device) {
     }
     JF_HIP(hipFree(nullptr));
     // set-up of the no-allocation entry point: this device's address of its static workspace
-    JF_TRY(noalloc_setup_current_device(nullptr));
+    int cur = 0;
+    JF_HIP(hipGetDevice(&cur));
+    JF_TRY(noalloc_setup_device(cur, nullptr));
     return JFHIP_OK;
 }
 
@@ -285,6 +363,21 @@ int32_t jfhip_stream_release_workspace(jfhip_stream* s) {
 int32_t jfhip_cache_clear(void) {
     ntt_cache_clear();
     quotient_cache_clear();
+    // the FK23 transforms the live SRS handles keep (up to fk_cache_byte_cap() each)
+    std::lock_guard<std::mutex> lk(g_srs_mu);
+    for (jfhip_srs* s : g_srs_live) {
+        srs_release_fk_cache(s);
+        std::lock_guard<std::mutex> pl(s->prefix_mu);
+        for (jfhip_srs* p : s->prefixes) srs_release_fk_cache(p);
+    }
+    return JFHIP_OK;
+}
+
+int32_t jfhip_srs_release_caches(jfhip_srs* srs) {
+    if (!srs) return JFHIP_OK;
+    srs_release_fk_cache(srs);
+    std::lock_guard<std::mutex> pl(srs->prefix_mu);
+    for (jfhip_srs* p : srs->prefixes) srs_release_fk_cache(p);
     return JFHIP_OK;
 }
 
@@ -441,8 +534,9 @@ int32_t jfhip_srs_gen_for_testing(int32_t curve_id, const uint64_t* beta_mont, c
 
 int32_t jfhip_srs_free(jfhip_srs* srs) {
     if (!srs) return JFHIP_OK;
+    srs_unregister(srs);
     for (jfhip_srs* p : srs->prefixes) (void)jfhip_srs_free(p);
-    for (auto& kv : srs->fk_dft) (void)hipFree(kv.second);
+    srs_release_fk_cache(srs);
     if (srs->table) (void)hipFree(srs->table);
     delete srs;
     return JFHIP_OK;
@@ -552,6 +646,7 @@ static int32_t msm_device_locked(const jfhip_srs* srs, size_t offset, const void
 
 int32_t jfhip_msm_device(const jfhip_srs* srs, size_t offset, const void* d_scalars, size_t n, void* d_out,
                          jfhip_stream* stream) {
+    MarkerRange mr("Committing to polynomial of degree %zu (device scalars)", n ? n - 1 : 0);
     JF_TRY(check_msm_range(srs, offset, n));
     if ((n && !d_scalars) || !d_out) {
         set_error("null argument");
@@ -694,6 +789,7 @@ static int32_t msm_batch_fused_locked(const jfhip_srs* srs, const size_t* offset
 
 int32_t jfhip_msm_batch_partial_device(const jfhip_srs* srs, const size_t* offsets, const void* const* d_scalars,
                                        const size_t* lens, size_t batch, void* d_out_xyzz, jfhip_stream* stream) {
+    MarkerRange mr("batch commit %zu polynomials (partial sums of a point range)", batch);
     if (!srs) {
         set_error("null SRS handle");
         return JFHIP_ERR_INVALID;
@@ -725,6 +821,7 @@ int32_t jfhip_msm_batch_partial_device(const jfhip_srs* srs, const size_t* offse
 
 int32_t jfhip_msm_batch_device(const jfhip_srs* srs, const void* const* d_scalars, const size_t* lens, size_t batch,
                                void* d_out, jfhip_stream* stream) {
+    MarkerRange mr("batch commit %zu polynomials (device scalars)", batch);
     if (!srs) {
         set_error("null SRS handle");
         return JFHIP_ERR_INVALID;
@@ -776,6 +873,7 @@ int32_t jfhip_msm_small(int32_t curve_id, const uint64_t* points_xy, const uint6
 
 int32_t jfhip_msm_batch(const jfhip_srs* srs, const uint64_t* const* scalars, const size_t* lens, size_t batch,
                         void* out_xy, uint8_t* out_inf, jfhip_stream* stream) {
+    MarkerRange mr("batch commit %zu polynomials", batch);
     if (!srs) {
         set_error("null SRS handle");
         return JFHIP_ERR_INVALID;
@@ -824,6 +922,7 @@ int32_t jfhip_msm_batch(const jfhip_srs* srs, const uint64_t* const* scalars, co
 
 int32_t jfhip_msm(const jfhip_srs* srs, size_t offset, const uint64_t* scalars, size_t n, void* out_xy,
                   uint8_t* out_inf, jfhip_stream* stream) {
+    MarkerRange mr("Committing to polynomial of degree %zu", n ? n - 1 : 0);
     JF_TRY(check_msm_range(srs, offset, n));
     if ((n && !scalars) || !out_xy || !out_inf) {
         set_error("null argument");
@@ -886,6 +985,7 @@ int32_t jfhip_msm(const jfhip_srs* srs, size_t offset, const uint64_t* scalars, 
 
 int32_t jfhip_kzg_open(const jfhip_srs* srs, const uint64_t* coeffs, size_t n, const uint64_t* point, void* out_xy,
                        uint8_t* out_inf, uint64_t* out_eval, jfhip_stream* stream) {
+    MarkerRange mr("Opening polynomial of degree %zu", n ? n - 1 : 0);
     if (!srs || !point || !out_xy || !out_inf || !out_eval || (n && !coeffs)) {
         set_error("null argument");
         return JFHIP_ERR_INVALID;
@@ -929,6 +1029,7 @@ int32_t jfhip_kzg_open(const jfhip_srs* srs, const uint64_t* coeffs, size_t n, c
 int32_t jfhip_kzg_multi_point_open(const jfhip_srs* srs, const uint64_t* coeffs, size_t n, const uint64_t* points,
                                    size_t num_points, void* out_xy, uint8_t* out_inf, uint64_t* out_evals,
                                    jfhip_stream* stream) {
+    MarkerRange mr("Opening polynomial of degree %zu at %zu points", n ? n - 1 : 0, num_points);
     if (num_points == 0) {
         set_error("no point to evaluate and open");   // mod.rs:421-425
         return JFHIP_ERR_INVALID;
@@ -1134,6 +1235,8 @@ int32_t jfhip_mle_open(const jfhip_srs* const* levels, size_t nv, const uint64_t
 
 int32_t jfhip_ntt_device(int32_t curve_id, void* d_data, uint32_t log_n, size_t batch, int32_t inverse,
                          const uint64_t* coset, size_t in_len, jfhip_stream* stream) {
+    MarkerRange mr("%s%sFFT of %zu polynomials over a domain of size 2^%u", coset ? "coset " : "", inverse ? "i" : "", batch,
+                   log_n);
     JF_TRY(check_curve(curve_id));
     if (batch && !d_data) {
         set_error("null data pointer");
@@ -1146,6 +1249,8 @@ int32_t jfhip_ntt_device(int32_t curve_id, void* d_data, uint32_t log_n, size_t 
 
 int32_t jfhip_ntt(int32_t curve_id, uint64_t* data, uint32_t log_n, size_t batch, int32_t inverse,
                   const uint64_t* coset, size_t in_len, jfhip_stream* stream) {
+    MarkerRange mr("%s%sFFT of %zu polynomials over a domain of size 2^%u (host data)", coset ? "coset " : "",
+                   inverse ? "i" : "", batch, log_n);
     JF_TRY(check_curve(curve_id));
     if (batch == 0) return JFHIP_OK;
     if (!data) {
@@ -1449,6 +1554,18 @@ int32_t jfhip_g1_op(int32_t curve_id, int32_t op, const uint64_t* P, const uint6
 int32_t jfhip_probe(int32_t kind, int32_t arg, double* out_rate) {
     if (!out_rate) return JFHIP_ERR_INVALID;
     return probe(kind, arg, out_rate);
+}
+
+int32_t jfhip_marker_push(const char* name) {
+    const Roctx& r = roctx();
+    if (r.push && name) r.push(name);
+    return JFHIP_OK;
+}
+
+int32_t jfhip_marker_pop(void) {
+    const Roctx& r = roctx();
+    if (r.pop) r.pop();
+    return JFHIP_OK;
 }
 
 int32_t jfhip_set_profiling(int32_t enabled) {

@@ -53,13 +53,24 @@ constexpr int MAX_PHASES = 16;
 // which waits for enqueued work).  Val needs: size_t bytes() const; void release().
 using Lease = std::shared_ptr<void>;
 size_t cache_byte_cap();   // JFHIP_CACHE_BYTES, default 8 GiB per cache
+size_t fk_cache_byte_cap();   // JFHIP_FK_CACHE_BYTES, default 4 GiB per SRS handle
 
 template <class Key, class Val>
 struct DevCache {
+    // one table set being built or built.  m is held by the builder for the length of build(): threads that want the same
+    // key wait on it; threads that want other keys (or other devices) never do -- the cache-wide mutex covers only the
+    // map bookkeeping, not allocation, kernel launches or stream synchronisation.
+    struct Slot {
+        std::mutex m;
+        int32_t rc = JFHIP_OK;
+        Val v{};
+    };
     struct Entry {
-        Val v;
+        std::shared_ptr<Slot> slot;
         uint64_t last = 0;
         int pins = 0;
+        size_t bytes = 0;    // accounted size: the caller's hint while building, v.bytes() afterwards
+        bool built = false;
     };
     std::mutex mu;
     std::map<Key, Entry> m;
@@ -71,56 +82,96 @@ struct DevCache {
         auto it = m.find(k);
         if (it != m.end() && it->second.pins > 0) it->second.pins--;
     }
-    // evict unpinned entries, oldest first, until `need` more bytes fit under the cap (caller holds mu)
-    void make_room(size_t need) {
+    // unlink unpinned, built entries, oldest first, until `need` more bytes fit under the cap (caller holds mu); the
+    // device memory itself is freed by the caller AFTER it has dropped mu (hipFree synchronises the device)
+    void make_room(size_t need, std::vector<std::shared_ptr<Slot>>& victims) {
         const size_t cap = cache_byte_cap();
         while (total + need > cap) {
             auto victim = m.end();
             for (auto it = m.begin(); it != m.end(); ++it)
-                if (it->second.pins == 0 && (victim == m.end() || it->second.last < victim->second.last)) victim = it;
+                if (it->second.pins == 0 && it->second.built &&
+                    (victim == m.end() || it->second.last < victim->second.last))
+                    victim = it;
             if (victim == m.end()) return;  // everything is in use: grow past the cap rather than fail
-            total -= victim->second.v.bytes();
-            victim->second.v.release();
+            total -= victim->second.bytes;
+            victims.push_back(victim->second.slot);
             m.erase(victim);
         }
     }
     template <class Build>
     int32_t get(const Key& k, Val* out, Lease* lease, size_t bytes_hint, Build build) {
-        std::lock_guard<std::mutex> lk(mu);
-        auto it = m.find(k);
-        if (it == m.end()) {
-            make_room(bytes_hint);
-            Val v;
-            int32_t rc = build(&v);
-            if (rc != JFHIP_OK) {
-                v.release();  // partial allocations of a failed build
-                return rc;
+        std::shared_ptr<Slot> slot;
+        std::vector<std::shared_ptr<Slot>> victims;
+        bool builder = false;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            auto it = m.find(k);
+            if (it == m.end()) {
+                make_room(bytes_hint, victims);
+                Entry e;
+                e.slot = std::make_shared<Slot>();
+                e.bytes = bytes_hint;
+                e.slot->m.lock();   // uncontended: nobody else has seen the slot yet (lock order: mu, then Slot::m)
+                it = m.emplace(k, e).first;
+                total += bytes_hint;
+                builder = true;
             }
-            Entry e;
-            e.v = v;
-            it = m.emplace(k, e).first;
-            total += v.bytes();
+            it->second.last = ++tick;
+            it->second.pins++;
+            slot = it->second.slot;
         }
-        it->second.last = ++tick;
-        it->second.pins++;
-        *out = it->second.v;
+        for (auto& v : victims) v->v.release();
+        if (builder) {
+            slot->rc = build(&slot->v);
+            if (slot->rc != JFHIP_OK) slot->v.release();  // partial allocations of a failed build
+            const int32_t rc = slot->rc;
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                auto it = m.find(k);
+                if (it != m.end() && it->second.slot == slot) {
+                    total -= it->second.bytes;
+                    if (rc == JFHIP_OK) {
+                        it->second.bytes = slot->v.bytes();
+                        it->second.built = true;
+                        total += it->second.bytes;
+                    } else {
+                        m.erase(it);   // waiters hold the slot and read its rc
+                    }
+                }
+            }
+            slot->m.unlock();
+            if (rc != JFHIP_OK) return rc;
+        } else {
+            std::lock_guard<std::mutex> wait(slot->m);   // until the builder is done
+            if (slot->rc != JFHIP_OK) {
+                unpin(k);
+                set_error("device table build failed on another thread (status %d)", slot->rc);
+                return slot->rc;
+            }
+        }
+        *out = slot->v;
         *lease = Lease(nullptr, [this, k](void*) { this->unpin(k); });
         return JFHIP_OK;
     }
     // free every entry that no call holds
     void clear() {
-        std::lock_guard<std::mutex> lk(mu);
-        for (auto it = m.begin(); it != m.end();) {
-            if (it->second.pins == 0) {
-                total -= it->second.v.bytes();
-                it->second.v.release();
-                it = m.erase(it);
-            } else ++it;
+        std::vector<std::shared_ptr<Slot>> victims;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (auto it = m.begin(); it != m.end();) {
+                if (it->second.pins == 0 && it->second.built) {
+                    total -= it->second.bytes;
+                    victims.push_back(it->second.slot);
+                    it = m.erase(it);
+                } else ++it;
+            }
         }
+        for (auto& v : victims) v->v.release();
     }
 };
 void ntt_cache_clear();
 void quotient_cache_clear();
+void srs_release_fk_cache(const jfhip_srs* srs);   // ecntt.hip
 
 }  // namespace jf
 
@@ -167,8 +218,18 @@ struct jfhip_srs {
     mutable std::mutex prefix_mu;
     mutable std::vector<jfhip_srs*> prefixes;
     // FK23 (ecntt.hip): the group-element DFT of the first d points, zero-extended to 2^log_M, depends on the SRS only;
-    // kept per (d, log_M) after the first multi-open of that shape (2^log_M saturated XYZZ elements), under prefix_mu
-    mutable std::map<std::pair<uint32_t, uint32_t>, uint32_t*> fk_dft;
+    // kept per (d, log_M) after the first multi-open of that shape (2^log_M saturated XYZZ elements), under its own
+    // mutex fk_mu (never held while a transform runs), bounded by bytes (fk_cache_byte_cap(), least recently used out)
+    // and released by jfhip_srs_release_caches / jfhip_cache_clear / jfhip_srs_free
+    struct FkEntry {
+        uint32_t* p = nullptr;
+        size_t bytes = 0;
+        uint64_t last = 0;
+    };
+    mutable std::mutex fk_mu;
+    mutable std::map<std::pair<uint32_t, uint32_t>, FkEntry> fk_dft;
+    mutable size_t fk_bytes = 0;
+    mutable uint64_t fk_tick = 0;
 };
 
 namespace jf {
@@ -238,7 +299,7 @@ int32_t plonk_lookup_merge_device(int32_t curve, uint32_t log_n, const uint32_t*
                                   const uint64_t* tau, uint32_t* out_table, uint32_t* out_lookup, jfhip_stream* st);
 int32_t open_witness_device(int32_t curve, const uint32_t* d_coeffs, size_t n, const uint32_t* d_point,
                             uint32_t* d_witness, uint32_t* d_eval, jfhip_stream* st);
-int32_t noalloc_setup_current_device(uint32_t** out);
+int32_t noalloc_setup_device(int dev, uint32_t** out);
 int32_t poly_divide_linear_noalloc(int32_t curve, const uint32_t* d_coeffs, size_t n, const uint64_t* point_mont,
                                    uint32_t* d_out, hipStream_t stream);
 int32_t witness_gather_device(const uint32_t* d_witness, size_t num_vars, const uint32_t* d_wire_variables, size_t count,

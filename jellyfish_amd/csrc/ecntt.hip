@@ -197,30 +197,59 @@ static int32_t multi_open_rou_t(const jfhip_srs* srs, const uint32_t* d_coeffs, 
     uint32_t* T = tmp.b.as<uint32_t>();
     hipLaunchKernelGGL((k_ec_minv<Cv>), dim3(1), dim3(64), 0, st->s, log_M, par.b.as<uint32_t>());
     // DFT_M(S): S_k for k < d.  It depends on the SRS only: computed on the first multi-open of this shape, then copied
-    // from the handle (a third of the group transforms of a call)
+    // from the handle (a third of the group transforms of a call).  fk_mu covers the look-up and the publication only:
+    // the transform itself runs unlocked, so commits and other opens against the handle are never held up by it.
+    const size_t dft_bytes = (size_t)M * XZ * 4;
+    const auto key = std::make_pair(d, log_M);
+    bool have = false;
     {
-        std::lock_guard<std::mutex> lk(srs->prefix_mu);
-        const auto key = std::make_pair(d, log_M);
+        std::lock_guard<std::mutex> lk(srs->fk_mu);
         auto it = srs->fk_dft.find(key);
-        if (it == srs->fk_dft.end()) {
-            hipLaunchKernelGGL((k_ec_from_srs<Cv>), dim3((M + 255) / 256), dim3(256), 0, st->s, srs->table, (int)srs->f29, d,
-                               M, P);
-            JF_TRY(ec_ntt_t<Cv>(srs->curve, P, T, tw.b.as<uint32_t>(), log_M, 0, st));
-            uint32_t* keep = nullptr;
-            if (srs->fk_dft.size() >= 8) {
-                // a caller cycling through many degrees: the handle keeps the first eight shapes only
-            } else if (hipMalloc(&keep, (size_t)M * XZ * 4) == hipSuccess) {
-                // other host threads read it without any ordering on this stream: complete before it is published
-                if (hipMemcpyAsync(keep, P, (size_t)M * XZ * 4, hipMemcpyDeviceToDevice, st->s) == hipSuccess &&
-                    hipStreamSynchronize(st->s) == hipSuccess)
-                    srs->fk_dft[key] = keep;
-                else
-                    (void)hipFree(keep);
+        if (it != srs->fk_dft.end()) {
+            // enqueued under the lock: a release (hipFree, which waits for enqueued work) cannot overtake the copy
+            JF_HIP(hipMemcpyAsync(P, it->second.p, dft_bytes, hipMemcpyDeviceToDevice, st->s));
+            it->second.last = ++srs->fk_tick;
+            have = true;
+        }
+    }
+    if (!have) {
+        hipLaunchKernelGGL((k_ec_from_srs<Cv>), dim3((M + 255) / 256), dim3(256), 0, st->s, srs->table, (int)srs->f29, d, M,
+                           P);
+        JF_TRY(ec_ntt_t<Cv>(srs->curve, P, T, tw.b.as<uint32_t>(), log_M, 0, st));
+        uint32_t* keep = nullptr;
+        if (dft_bytes > fk_cache_byte_cap()) {
+            // larger than the whole budget (2^27 points are 16 / 24 GiB): recomputed per call, never pinned in HBM
+        } else if (hipMalloc(&keep, dft_bytes) == hipSuccess) {
+            // other host threads read it without any ordering on this stream: complete before it is published
+            bool ok = hipMemcpyAsync(keep, P, dft_bytes, hipMemcpyDeviceToDevice, st->s) == hipSuccess &&
+                      hipStreamSynchronize(st->s) == hipSuccess;
+            std::vector<uint32_t*> drop;
+            if (ok) {
+                std::lock_guard<std::mutex> lk(srs->fk_mu);
+                if (srs->fk_dft.count(key)) {
+                    drop.push_back(keep);   // another thread published the same shape meanwhile
+                } else {
+                    while (srs->fk_bytes + dft_bytes > fk_cache_byte_cap() && !srs->fk_dft.empty()) {
+                        auto victim = srs->fk_dft.begin();
+                        for (auto j = srs->fk_dft.begin(); j != srs->fk_dft.end(); ++j)
+                            if (j->second.last < victim->second.last) victim = j;
+                        srs->fk_bytes -= victim->second.bytes;
+                        drop.push_back(victim->second.p);
+                        srs->fk_dft.erase(victim);
+                    }
+                    jfhip_srs::FkEntry e;
+                    e.p = keep;
+                    e.bytes = dft_bytes;
+                    e.last = ++srs->fk_tick;
+                    srs->fk_dft[key] = e;
+                    srs->fk_bytes += dft_bytes;
+                }
             } else {
-                (void)hipGetLastError();   // no room to keep it: recomputed next time
+                drop.push_back(keep);
             }
+            for (uint32_t* q : drop) (void)hipFree(q);
         } else {
-            JF_HIP(hipMemcpyAsync(P, it->second, (size_t)M * XZ * 4, hipMemcpyDeviceToDevice, st->s));
+            (void)hipGetLastError();   // no room to keep it: recomputed next time
         }
     }
     // DFT_M(r), r_m = f_{d - m}
@@ -249,6 +278,18 @@ int32_t multi_open_rou_device(const jfhip_srs* srs, const uint32_t* d_coeffs, si
     if (srs->curve == JFHIP_BN254)
         return multi_open_rou_t<Bn254G1>(srs, d_coeffs, ncoeffs, log_dom, num_points, d_out, rec_bytes, log_M, st);
     return multi_open_rou_t<Bls381G1>(srs, d_coeffs, ncoeffs, log_dom, num_points, d_out, rec_bytes, log_M, st);
+}
+
+// give back the FK23 transforms a handle keeps (jfhip_srs_release_caches, jfhip_cache_clear, jfhip_srs_free)
+void srs_release_fk_cache(const jfhip_srs* srs) {
+    std::vector<uint32_t*> drop;
+    {
+        std::lock_guard<std::mutex> lk(srs->fk_mu);
+        for (auto& kv : srs->fk_dft) drop.push_back(kv.second.p);
+        srs->fk_dft.clear();
+        srs->fk_bytes = 0;
+    }
+    for (uint32_t* q : drop) (void)hipFree(q);
 }
 
 }  // namespace jf

@@ -38,7 +38,7 @@ struct NttTables {
     uint32_t* ch = nullptr;        // s0 * h^(i 2^a)
     uint32_t a = 0;
     int scale_mode = 0;  // 0 none, 1 constant n^-1, 2 two-level table
-    uint32_t nbytes = 0;
+    size_t nbytes = 0;
     size_t bytes() const { return nbytes; }
     void release() {
         uint32_t** all[] = {&params, &tw_small, &tl, &th, &cl, &ch};
@@ -733,7 +733,7 @@ static int32_t build_tables(uint32_t log_n, int inverse, const uint64_t* coset_m
     const uint32_t lo_n = 1u << t.a, hi_n = 1u << (log_n - t.a);
     const bool has_coset = coset_mont != nullptr;
     t.scale_mode = has_coset ? 2 : (inverse ? 1 : 0);
-    t.nbytes = (uint32_t)((4 + 256 + (size_t)(has_coset ? 2 : 1) * (lo_n + hi_n)) * N * 4);
+    t.nbytes = (size_t)((4 + 256 + (size_t)(has_coset ? 2 : 1) * (lo_n + hi_n)) * N * 4);
     JF_HIP(hipMalloc(&t.params, 4 * N * 4));
     JF_HIP(hipMalloc(&t.tw_small, 256 * N * 4));
     JF_HIP(hipMalloc(&t.tl, (size_t)lo_n * N * 4));

@@ -170,23 +170,36 @@ static __device__ __align__(256) uint32_t scratch[NOALLOC_SCRATCH_WORDS];
 constexpr int NOALLOC_MAX_DEVICES = 64;
 static std::mutex g_noalloc_mu;
 static uint32_t* g_noalloc_ptr[NOALLOC_MAX_DEVICES] = {};
+// Calls share their GPU's array.  Two calls on different streams of one GPU are ORDERED, not raced: a per-device host
+// mutex serialises the enqueue, and the next call's stream waits on an event recorded after the previous call's last
+// kernel (events are created at set-up; waiting and recording allocate nothing).  A stream under graph capture takes no
+// part in that (an event recorded outside the capture cannot be waited on inside it): such callers serialise themselves.
+static std::mutex g_noalloc_dev_mu[NOALLOC_MAX_DEVICES];
+static hipEvent_t g_noalloc_done[NOALLOC_MAX_DEVICES] = {};
+static bool g_noalloc_recorded[NOALLOC_MAX_DEVICES] = {};
 
-// once per device, with that device current: the device address of this GPU's copy of `scratch`
-int32_t noalloc_setup_current_device(uint32_t** out) {
-    int dev = -1;
-    JF_HIP(hipGetDevice(&dev));
+// once per device: the device address of THAT GPU's copy of `scratch` (taken with the device current, restored after)
+int32_t noalloc_setup_device(int dev, uint32_t** out) {
     if (dev < 0 || dev >= NOALLOC_MAX_DEVICES) {
         set_error("no-alloc entry point: device ordinal %d beyond the %d supported", dev, NOALLOC_MAX_DEVICES);
         return JFHIP_ERR_INVALID;
     }
     std::lock_guard<std::mutex> lk(g_noalloc_mu);
     if (!g_noalloc_ptr[dev]) {
+        int cur = -1;
+        JF_HIP(hipGetDevice(&cur));
+        if (cur != dev) JF_HIP(hipSetDevice(dev));
         uint32_t* ptr = nullptr;
-        JF_HIP(hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch)));
+        hipError_t e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
+        hipEvent_t ev = nullptr;
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        if (cur != dev) (void)hipSetDevice(cur);
+        JF_HIP(e);
         if (!ptr) {
             set_error("hipGetSymbolAddress(scratch) returned a null address on device %d", dev);
             return JFHIP_ERR_DEVICE;
         }
+        g_noalloc_done[dev] = ev;
         g_noalloc_ptr[dev] = ptr;
     }
     if (out) *out = g_noalloc_ptr[dev];
@@ -204,14 +217,32 @@ int32_t poly_divide_linear_noalloc(int32_t curve, const uint32_t* d_coeffs, size
         set_error("no-alloc divide: workspace bound violated for n = %zu", n);
         return JFHIP_ERR_INVALID;
     }
+    // the array of the GPU that owns `stream` (not of the calling thread's current device: a thread whose current
+    // device is B may pass a stream of device A, and the kernels run where the stream lives)
+    hipDevice_t sdev = 0;
+    JF_HIP(hipStreamGetDevice(stream, &sdev));
+    const int dev = (int)sdev;
     uint32_t* ptr = nullptr;
-    JF_TRY(noalloc_setup_current_device(&ptr));
+    JF_TRY(noalloc_setup_device(dev, &ptr));
     FrArg z;
     memcpy(z.v, point_mont, 32);
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+    if (!capturing) (void)hipGetLastError();
+    std::lock_guard<std::mutex> lk(g_noalloc_dev_mu[dev]);
+    if (!capturing && g_noalloc_recorded[dev]) JF_HIP(hipStreamWaitEvent(stream, g_noalloc_done[dev], 0));
     // nothing in the workspace has to start at zero: every level writes its chunk values and suffixes before the next
     // kernel reads them, and the top chunk's carry is the constant 0, not a stored value
-    if (curve == JFHIP_BN254) return open_witness_ws<Bn254Fr>(d_coeffs, n, nullptr, &z, ptr, d_out, stream);
-    return open_witness_ws<Bls381Fr>(d_coeffs, n, nullptr, &z, ptr, d_out, stream);
+    int32_t rc;
+    if (curve == JFHIP_BN254) rc = open_witness_ws<Bn254Fr>(d_coeffs, n, nullptr, &z, ptr, d_out, stream);
+    else rc = open_witness_ws<Bls381Fr>(d_coeffs, n, nullptr, &z, ptr, d_out, stream);
+    if (!capturing) {
+        // recorded on every path: kernels enqueued before a launch error still use the array
+        hipError_t e = hipEventRecord(g_noalloc_done[dev], stream);
+        if (e == hipSuccess) g_noalloc_recorded[dev] = true;
+        else if (rc == JFHIP_OK) JF_HIP(e);
+    }
+    return rc;
 }
 
 // ---- batched evaluation at one point --------------------------------------------------------------

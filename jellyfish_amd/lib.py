@@ -34,11 +34,11 @@ SYMBOLS = [
     "jfhip_init", "jfhip_shutdown", "jfhip_cache_clear", "jfhip_stream_release_workspace", "jfhip_last_error", "jfhip_device_count", "jfhip_stream_create", "jfhip_stream_destroy",
     "jfhip_stream_sync", "jfhip_stream_raw", "jfhip_stream_wrap", "jfhip_srs_load", "jfhip_srs_load_device",
     "jfhip_srs_load_serialized", "jfhip_msm_small",
-    "jfhip_srs_gen_for_testing", "jfhip_srs_free", "jfhip_srs_len", "jfhip_srs_window_bits", "jfhip_srs_read",
+    "jfhip_srs_gen_for_testing", "jfhip_srs_free", "jfhip_srs_release_caches", "jfhip_srs_len", "jfhip_srs_window_bits", "jfhip_srs_read",
     "jfhip_msm", "jfhip_msm_batch", "jfhip_msm_batch_device", "jfhip_msm_device", "jfhip_msm_partial_device", "jfhip_msm_batch_partial_device", "jfhip_g1_sum_partials",
     "jfhip_kzg_open", "jfhip_kzg_multi_point_open", "jfhip_kzg_multi_open_rou", "jfhip_mle_open", "jfhip_mle_fold_device", "jfhip_ntt", "jfhip_ntt_device", "jfhip_plonk_quotient_turbo_device", "jfhip_plonk_quotient_ultra_device", "jfhip_plonk_quotient_coset_device", "jfhip_plonk_quotient_masked_device", "jfhip_plonk_perm_product_device", "jfhip_plonk_lookup_product_device", "jfhip_plonk_lookup_merge_device", "jfhip_plonk_lookup_sorted_device", "jfhip_witness_gather_device", "jfhip_poly_divide_linear_device", "jfhip_poly_divide_linear_noalloc_device",
     "jfhip_poly_lincomb_device", "jfhip_poly_eval_batch_device", "jfhip_field_op", "jfhip_g1_op", "jfhip_probe",
-    "jfhip_set_profiling", "jfhip_last_phase_ms", "jfhip_phase_name", "jfhip_keccak_f1600",
+    "jfhip_marker_push", "jfhip_marker_pop", "jfhip_set_profiling", "jfhip_last_phase_ms", "jfhip_phase_name", "jfhip_keccak_f1600",
 ]
 
 
@@ -199,6 +199,10 @@ class Srs:
         out = np.zeros((n, 2 * FQ_LIMBS64[self.curve]), dtype=np.uint64)
         _check(load_library().jfhip_srs_read(self.h, ctypes.c_size_t(offset), ctypes.c_size_t(n), _p(out)))
         return out
+
+    def release_caches(self):
+        """give back the FK23 transforms this handle keeps (rebuilt on demand)"""
+        _check(load_library().jfhip_srs_release_caches(self.h))
 
     def free(self):
         if self.h:
@@ -524,6 +528,21 @@ def probe(kind: int, arg: int = 0) -> float:
     r = ctypes.c_double(0)
     _check(load_library().jfhip_probe(kind, arg, ctypes.byref(r)))
     return r.value
+
+
+class marker:
+    """roctx range around a block (jfhip_marker_push / pop): a no-op unless JFHIP_MARKERS=1 and a roctx library exists"""
+
+    def __init__(self, name: str):
+        self.name = name.encode()
+
+    def __enter__(self):
+        load_library().jfhip_marker_push(self.name)
+        return self
+
+    def __exit__(self, *exc):
+        load_library().jfhip_marker_pop()
+        return False
 
 
 def set_profiling(enabled: bool):

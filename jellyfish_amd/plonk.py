@@ -23,6 +23,7 @@ proofs verify) in tests/test_gpu_plonk.py.
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass, field
 
 import numpy as np
@@ -48,6 +49,9 @@ class PlonkError(RuntimeError):
 
 
 PROFILE = None   # set to a dict to collect a per-round wall-clock breakdown of prove() (adds device syncs)
+# JFHIP_MARKERS=1: a roctx mark at the end of every step of prove() (with a device sync, so that the kernels of a step lie
+# between its mark and the previous one): `rocprofv3 --kernel-trace --marker-trace` then segments a proof by round
+MARKERS = os.environ.get("JFHIP_MARKERS", "0") not in ("", "0")
 
 
 def _sel(q_lc=(0, 0, 0, 0), q_mul=(0, 0), q_hash=(0, 0, 0, 0), q_o=0, q_c=0, q_ecc=0):
@@ -1163,11 +1167,20 @@ class PlonkKzgSnark:
         t_last = [_time.perf_counter()]
 
         def tick(name):
+            if MARKERS:
+                torch.cuda.synchronize()
+                with L.marker("prove step end: " + name):
+                    pass
             if PROFILE is not None:
                 torch.cuda.synchronize()
                 now = _time.perf_counter()
                 PROFILE[name] = round(PROFILE.get(name, 0.0) + (now - t_last[0]) * 1e3, 3)
                 t_last[0] = now
+
+        if MARKERS:
+            torch.cuda.synchronize()
+            with L.marker("prove step end: start"):
+                pass
 
         def draw(count: int) -> list:
             return [H.fr_rand(cp, rng) for _ in range(count)]

@@ -79,6 +79,7 @@ extern "C" {
         window_bits: i32,
         out: *mut *mut jfhip_srs,
     ) -> i32;
+    pub fn jfhip_srs_release_caches(srs: *mut jfhip_srs) -> i32;
     pub fn jfhip_srs_free(srs: *mut jfhip_srs) -> i32;
     pub fn jfhip_srs_len(srs: *const jfhip_srs) -> usize;
     pub fn jfhip_srs_window_bits(srs: *const jfhip_srs) -> i32;
@@ -385,6 +386,8 @@ extern "C" {
     pub fn jfhip_g1_op(curve_id: i32, op: i32, p: *const u64, q: *const u64, out: *mut u64) -> i32;
     pub fn jfhip_keccak_f1600(state25: *mut u64) -> i32;
     pub fn jfhip_probe(kind: i32, arg: i32, out_rate: *mut f64) -> i32;
+    pub fn jfhip_marker_push(name: *const c_char) -> i32;
+    pub fn jfhip_marker_pop() -> i32;
     pub fn jfhip_set_profiling(enabled: i32) -> i32;
     pub fn jfhip_last_phase_ms(stream: *mut jfhip_stream, phases: *mut f64, cap: i32) -> i32;
     pub fn jfhip_phase_name(kind: i32, idx: i32) -> *const c_char;

@@ -16,10 +16,17 @@ LOG_N = 18
 
 def _bench(gpus: int) -> dict:
     env = dict(os.environ, JF_BENCH_REHEARSE="1", JF_BENCH_SECONDARY_TIMEOUT_S="240")
+    # N = 1: the headline only (the secondary single-GPU sections are the driver's full run); N = 2: headline + the
+    # weak-scaling extra key, no proofs
+    extra = ["--headline-only"] if gpus == 1 else ["--no-cpu-baseline", "--no-ntt", "--no-prove", "--ultra-log-n", "0"]
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--log-n", str(LOG_N), "--steps", "2",
-           "--warmup", "1", "--no-cpu-baseline", "--no-ntt", "--no-prove", "--ultra-log-n", "0"]
+           "--warmup", "1"] + extra
     p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=280)
-    assert p.returncode == 0, p.stderr[-2000:]
+    if p.returncode != 0:   # keep the whole output where a GPU-box run brings it back
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "bench_rehearsal_%d.err" % gpus), "w") as f:
+            f.write(p.stdout + "\n==== stderr ====\n" + p.stderr)
+    assert p.returncode == 0, p.stderr[-6000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
     return json.loads(lines[0])

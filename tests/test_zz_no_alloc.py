@@ -77,3 +77,36 @@ def test_no_alloc_divide_at_the_limit(hip):
     ref2 = _divide(hip, cv, d_in, 1000, z, st, noalloc=False)
     assert (got2 == ref2).all()
     st.close()
+
+
+def test_no_alloc_divide_leaves_device_memory_unchanged_and_orders_streams(hip):
+    """the property the entry point exists for: after one warm-up call, a run of calls on fresh streams changes neither
+    the free device memory nor the streams' (empty) workspaces; and calls that overlap on two streams of one GPU, which
+    share the static array, are ordered by the library: both results stay exact"""
+    import torch
+
+    cv = R.BN254
+    n = 200000
+    coeffs = rand_fr_mont(cv, n, 4300)
+    zs = rand_fr_mont(cv, 2, 4301)
+    d_in = torch.from_numpy(coeffs.view(np.int64).reshape(-1)).cuda()
+    outs = [torch.zeros(n * 4, dtype=torch.int64, device="cuda") for _ in range(2)]
+    sts = [hip.Stream(), hip.Stream()]
+    hip.poly_divide_linear_noalloc_device(cv.curve_id, d_in.data_ptr(), n, zs[0], outs[0].data_ptr(), stream=sts[0])
+    sts[0].sync()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for rep in range(6):
+        for k in range(2):   # enqueued back to back on two streams: they overlap unless the library orders them
+            hip.poly_divide_linear_noalloc_device(cv.curve_id, d_in.data_ptr(), n, zs[k], outs[k].data_ptr(),
+                                                  stream=sts[k])
+    for st in sts:
+        st.sync()
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] == free0
+    for k in range(2):
+        q, ev = C.open_witness(cv.curve_id, coeffs, zs[k])
+        got = outs[k].cpu().numpy().view(np.uint64).reshape(n, 4)
+        assert (got[0] == ev).all() and (got[1:] == q).all(), k
+    for st in sts:
+        st.close()
