@@ -430,7 +430,12 @@ int32_t jfhip_keccak_f1600(uint64_t *state25);
 
 /* Peak-rate probes used by bench.py for the roofline denominators:
  * kind 0: v_mad_u64_u32 multiply-adds/s (INT32 VALU), kind 1: device copy bytes/s,
- * kind 2: Montgomery multiplications/s of the field given in `arg` (field_id). */
+ * kind 2: Montgomery multiplications/s of the field given in `arg` (field_id); 3: the same on the kernels' 29-bit limbs;
+ * 4 / 5: random 64-byte gathers/s over a table of `arg` GiB (dependent / independent issue);
+ * 6: multiplications/s by a CONSTANT through the VALU (fp_mul_const29, the NTT's twiddle product; arg = field_id 0 or 2);
+ * 7: the same map through the int8 matrix cores (v_mfma_i32_32x32x32_i8 against the constant's Toeplitz byte matrix, with
+ *    the carry normalisations and the Montgomery step) as an instruction-mix lower bound -- an exploratory measurement
+ *    (DESIGN.md 3.3), no product path uses the matrix cores. */
 int32_t jfhip_probe(int32_t kind, int32_t arg, double *out_rate);
 
 /* Device markers.  With the environment variable JFHIP_MARKERS=1 the library brackets its entry points with roctx ranges

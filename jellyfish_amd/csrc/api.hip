@@ -635,9 +635,39 @@ int32_t jfhip_msm_partial_device(const jfhip_srs* srs, size_t offset, const void
                               (uint32_t*)d_out_xyzz, st);
 }
 
+static int32_t msm_batch_locked(const jfhip_srs* srs, const size_t* lens, size_t batch, uint8_t* d_res, size_t rec,
+                                jfhip_stream* st,
+                                const std::function<int32_t(size_t, jfhip_stream*, const void**)>& stage,
+                                const std::function<const jfhip_srs*(size_t)>& srs_of = nullptr,
+                                const size_t* offsets = nullptr);
+
 static int32_t msm_device_locked(const jfhip_srs* srs, size_t offset, const void* d_scalars, size_t n, void* d_out,
                                  jfhip_stream* st) {
     const size_t xz = 4 * (size_t)fq_bytes(srs->curve);
+    // Experiment switch (JFHIP_MSM_DEVICE_CHUNKS=2..4, default off): a large MSM as partial sums over point ranges on the
+    // lane streams, so that the bucket sort of one range (memory-bound) overlaps the bucket accumulation of the previous
+    // one (VALU-bound); the price is one more fix-up / fold / sum tree per range.
+    static const int dev_chunks = getenv("JFHIP_MSM_DEVICE_CHUNKS") ? atoi(getenv("JFHIP_MSM_DEVICE_CHUNKS")) : 1;
+    if (dev_chunks >= 2 && dev_chunks <= 4 && n >= ((size_t)1 << 22)) {
+        const size_t chunks = (size_t)dev_chunks;
+        JF_TRY(st->result.ensure(chunks * xz + 256));
+        std::vector<size_t> lens(chunks), offs(chunks);
+        const size_t per = (n + chunks - 1) / chunks;
+        for (size_t b = 0; b < chunks; b++) {
+            const size_t lo = b * per < n ? b * per : n, hi = (b + 1) * per < n ? (b + 1) * per : n;
+            offs[b] = offset + lo;
+            lens[b] = hi - lo;
+        }
+        const uint8_t* base = (const uint8_t*)d_scalars;
+        JF_TRY(msm_batch_locked(
+            srs, lens.data(), chunks, st->result.as<uint8_t>(), xz, st,
+            [&](size_t b, jfhip_stream*, const void** out) -> int32_t {
+                *out = base + (offs[b] - offset) * 32;
+                return JFHIP_OK;
+            },
+            nullptr, offs.data()));
+        return g1_sum_to_affine(srs->curve, st->result.as<uint32_t>(), chunks, (uint32_t*)d_out, st);
+    }
     JF_TRY(st->result.ensure(xz + 256));
     JF_TRY(msm_partial_device(srs_route(srs, offset + n, st), offset, (const uint32_t*)d_scalars, n,
                               st->result.as<uint32_t>(), st));
@@ -686,8 +716,7 @@ int32_t jfhip_g1_sum_partials(int32_t curve_id, const void* d_partials, size_t c
 static int32_t msm_batch_locked(const jfhip_srs* srs, const size_t* lens, size_t batch, uint8_t* d_res, size_t rec,
                                 jfhip_stream* st,
                                 const std::function<int32_t(size_t, jfhip_stream*, const void**)>& stage,
-                                const std::function<const jfhip_srs*(size_t)>& srs_of = nullptr,
-                                const size_t* offsets = nullptr) {
+                                const std::function<const jfhip_srs*(size_t)>& srs_of, const size_t* offsets) {
     size_t maxwork = 0;
     for (size_t b = 0; b < batch; b++) {
         const size_t w = lens[b] * (size_t)(srs_of ? srs_of(b) : srs)->W;
@@ -695,7 +724,8 @@ static int32_t msm_batch_locked(const jfhip_srs* srs, const size_t* lens, size_t
     }
     // lanes only pay off while the tails are a visible fraction of an MSM; each lane holds a workspace
     int lanes = 1;
-    if (batch > 1 && maxwork <= ((size_t)1 << 26)) lanes = batch < 3 ? (int)batch : 3;
+    static const bool force_lanes = getenv("JFHIP_MSM_LANES_FORCE") && getenv("JFHIP_MSM_LANES_FORCE")[0] == '1';
+    if (batch > 1 && (maxwork <= ((size_t)1 << 26) || force_lanes)) lanes = batch < 3 ? (int)batch : 3;
     if (lanes > 1) {
         if (!st->fork_ev) JF_HIP(hipEventCreateWithFlags(&st->fork_ev, hipEventDisableTiming));
         for (int i = 0; i < lanes - 1; i++) {

@@ -551,7 +551,10 @@ __global__ __launch_bounds__(256) void k_probe_mul(uint32_t iters, uint32_t seed
     if (x.v[0] == 0x12345u && y.v[1] == 0x777u) out[0] = x.v[2];
 }
 
+int32_t probe_const_mul(int32_t kind, int32_t arg, double* out);   // probe_mfma.hip: kinds 6 and 7
+
 int32_t probe(int32_t kind, int32_t arg, double* out) {
+    if (kind == 6 || kind == 7) return probe_const_mul(kind, arg, out);
     hipEvent_t e0, e1;
     JF_HIP(hipEventCreate(&e0));
     JF_HIP(hipEventCreate(&e1));

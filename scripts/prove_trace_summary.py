@@ -16,26 +16,28 @@ def cols(t):
     return [r[1] for r in c.execute("pragma table_info('%s')" % t)]
 
 
-# marker ranges: rocprofv3 stores roctx ranges as regions; find a table / view with a name and start / end columns
-marks = None
-tried = []
-for t in sorted(names, key=lambda n: (not n.startswith("regions"), not n.startswith("markers"), n)):
-    cs = cols(t)
-    if "start" in cs and "end" in cs and "name" in cs and t != "kernels" and not t.startswith("kernel"):
-        try:
-            rows = c.execute("select name, start, end from %s where name like 'prove step end:%%' order by start" % t).fetchall()
-        except sqlite3.Error as e:  # a view over tables this trace does not have
-            tried.append((t, repr(e)))
-            continue
-        tried.append((t, len(rows)))
-        if rows:
-            marks = (t, rows)
-            break
-if marks is None:
-    print("no marker rows found; tables / views:", names, "tried:", tried)
+# marker ranges: rocprofv3 stores roctx ranges in the view `regions` (category MARKER_CORE_RANGE_API, name =
+# roctxThreadRangeA, the message in the JSON column extdata)
+def message(ext, name):
+    try:
+        return json.loads(ext).get("message", name)
+    except Exception:
+        return name
+
+
+table = "regions"
+raw = c.execute("select name, extdata, start, end from regions where category like 'MARKER%' order by start").fetchall()
+ranges = [(message(ext, nm), s, e) for nm, ext, s, e in raw]
+rows = [r for r in ranges if r[0].startswith("prove step end:")]
+if not rows:
+    print("no marker rows found; tables / views:", names)
     sys.exit(3)
-table, rows = marks
-all_ranges = c.execute("select name, count(*), sum(end - start) from %s group by name order by 3 desc" % table).fetchall()
+agg = {}
+for nm, s, e in ranges:
+    a = agg.setdefault(nm, [0, 0])
+    a[0] += 1
+    a[1] += e - s
+all_ranges = sorted(((nm, v[0], v[1]) for nm, v in agg.items()), key=lambda r: -r[2])
 kern = c.execute("select name, start, end from kernels order by start").fetchall()
 # the last proof: from the last "start" mark on
 starts = [i for i, r in enumerate(rows) if r[0].endswith(": start")]
