@@ -43,6 +43,18 @@ BN254_R = 2188824287183927522224640574525727508854836440041603434369820418657580
 BLS_R = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
 
 
+def kernel_source_sha() -> str:
+    """fingerprint of the kernel sources: the committed PMC summaries (profiles/pmc_*latest.json) carry the one they were
+    taken on, and a bench line only presents their counters as current when it matches"""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in ("msm.hip", "ntt.hip", "fp.hpp", "fp29.hpp", "curve.hpp", "g29.hpp"):
+        with open(os.path.join(ROOT, "jellyfish_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def uniform_fr(n: int, seed: int, modulus: int) -> np.ndarray:
     """n uniform field elements (rejection sampling), as 4 x u64 limbs.  Any value < r is a valid
     Montgomery representative, so these are uniform scalars in the boundary's format."""
@@ -567,18 +579,26 @@ def main():
         achieved = macs / (acc_ms * 1e-3)
         alg_bytes = 96.0 * n  # 64 B affine point + 32 B scalar per point
         traffic = None
+        traffic_stale = None
+        src_sha = kernel_source_sha()
         pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc_path):
             try:
                 pmc = json.load(open(pmc_path))
                 if pmc.get("workload") in (out["config"]["workload"], out["config"]["workload"] + "_per_gpu"):
                     traffic = pmc.get("k_msm_accumulate_hbm_bytes")
-            except Exception:
-                traffic = None
+                    if pmc.get("kernel_source_sha") != src_sha:
+                        traffic_stale = "counters taken on kernel sources %s (head %s), this run is %s" % (
+                            pmc.get("kernel_source_sha"), pmc.get("git_head"), src_sha)
+            except (OSError, ValueError) as e:
+                traffic_stale = "profiles/pmc_latest.json unreadable: %r" % (e,)
         out["roofline"] = {
             "kernel": "k_msm_accumulate", "bound": "valu_int32",
             "achieved": round(achieved / 1e12, 4), "peak": round(mad_peak / 1e12, 4), "unit": "TMAC/s (v_mad_u64_u32)",
             "frac": round(achieved / mad_peak, 4), "traffic": traffic,
+            "traffic_source": "profiles/pmc_latest.json: rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE (separate passes), bytes per "
+                              "launch; a committed measurement, not taken in this run" + (
+                                  "" if not traffic_stale else "; STALE: " + traffic_stale),
             "algorithmic": "%d windows x 10 field mul x 136 MAC = %d MAC/point x 2^%d points" % (windows, macs_per_point, args.log_n),
             "avg_launch_ms": acc_ms,
             "peak_source": "v_mad_u64_u32 issue-rate micro-benchmark on this device (jfhip_probe 0); not in MI355X_MICROARCH.md",
@@ -589,23 +609,36 @@ def main():
         # VALU issue evidence from the rocprofv3 --pmc passes of the same workload (scripts/pmc_valu.sh, committed summary):
         # wave-instructions issued per shader cycle over the chip (1024 SIMDs; a wave64 v_mad_u64_u32 occupies its SIMD for
         # 4 cycles, 32-bit adds / shifts / moves for 2)
+        pv_all = None
         try:
-            pv = json.load(open(os.path.join(ROOT, "profiles", "pmc_valu_latest.json")))["kernels"]
+            pv_all = json.load(open(os.path.join(ROOT, "profiles", "pmc_valu_latest.json")))
+        except (OSError, ValueError) as e:
+            out["roofline"]["valu_pmc"] = {"error": "profiles/pmc_valu_latest.json unreadable: %r" % (e,)}
+        if pv_all is not None:
+            pv = pv_all["kernels"]
+            pv_current = pv_all.get("kernel_source_sha") == src_sha
             kk = [k for k in pv if "k_msm_accumulate" in k and "Bn254" in k]
             if kk:
                 d = pv[kk[0]]
                 cyc = d["GRBM_GUI_ACTIVE"] / 8.0
                 out["roofline"]["valu_pmc"] = {
-                    "kernel": kk[0], "source": "profiles/pmc_valu_latest.json (rocprofv3 --pmc, 2^24 points)",
+                    "kernel": kk[0], "source": "profiles/pmc_valu_latest.json (rocprofv3 --pmc, 2^24 points): a committed "
+                                               "measurement, not taken in this run",
+                    "taken_on": {"git_head": pv_all.get("git_head"), "kernel_source_sha": pv_all.get("kernel_source_sha")},
+                    "stale": (not pv_current),
+                    "executed_macs_per_launch": (d.get("SQ_INSTS_VALU_INT64", 0.0) * 64.0),
                     "SQ_INSTS_VALU_per_launch": d["SQ_INSTS_VALU"], "shader_cycles_per_launch": round(cyc),
                     "valu_wave_insts_per_cycle_chip": round(d["SQ_INSTS_VALU"] / cyc, 1),
                     "valu_insts_per_mixed_add": round(d["SQ_INSTS_VALU"] * 64.0 / (windows * float(1 << 24)), 1),
                     "int64_class_insts_per_launch": d.get("SQ_INSTS_VALU_INT64"),
                     "mad_issue_cycles_frac": round(d.get("SQ_INSTS_VALU_INT64", 0.0) * 4.0 / (cyc * 1024.0), 3),
                     "wait_inst_any_frac_of_wave_cycles": d.get("frac_of_wave_cycles:SQ_WAIT_INST_ANY"),
+                    "valu_issue_frac": round(d["SQ_INSTS_VALU"] / cyc / 256.0, 3),
+                    "valu_issue_note": "wave-instructions per shader cycle over the chip / 256 (1024 SIMDs, one wave64 "
+                                       "instruction per 4 cycles each): how close the kernel is to the VALU issue limit; "
+                                       "executed_macs counts the v_mad_u64_u32 the kernel issues (29-bit limbs: 171 per "
+                                       "product + 9 v_mul_lo) against the 136-per-product convention of `algorithmic`",
                 }
-        except Exception:
-            pass
         # second wall of this kernel: every mixed addition gathers one random 64-byte table point.  jfhip_probe(4, GiB)
         # measures the device's random 64-byte gather rate over a table of the same size, nothing else running.
         table_gib = max(1, int(round(windows * n * 64 / 2**30)))
@@ -649,6 +682,28 @@ def main():
                     "ntt_8x2^22_bls_hbm_bytes_per_transform_upper")
             except Exception:
                 ntt_traffic = None
+            # VALU view: the transform is bound by INT32 multiply-adds long before HBM.  Algorithmic products per element
+            # = (log2 n) / 2 butterfly twiddles + 1 coset / n^-1 scaling, 136 MAC each (the convention of the MSM roofline).
+            ntt_prods = log_m / 2.0 + 1.0
+            ntt_insts = None
+            if pv_all is not None:
+                try:
+                    per_pass = [v["SQ_INSTS_VALU"] * v.get("launches", 1) for k, v in pv_all["kernels"].items()
+                                if "k_ntt_pass_r8" in k and "Bls381Fr" in k]
+                    # scripts/pmc_run.py runs 4 transforms of 8 x 2^22 elements
+                    ntt_insts = {"SQ_INSTS_VALU_per_element_and_transform": round(sum(per_pass) * 64.0 / (4.0 * batch * m), 1),
+                                 "source": "profiles/pmc_valu_latest.json (committed measurement)",
+                                 "stale": pv_all.get("kernel_source_sha") != src_sha}
+                except (KeyError, TypeError):
+                    ntt_insts = None
+            for k in res_ntt:
+                t_s = res_ntt[k]["ms"] * 1e-3
+                a = ntt_prods * 136.0 * batch * m / t_s
+                res_ntt[k]["roofline"]["valu_view"] = {
+                    "bound": "valu_int32", "achieved": round(a / 1e12, 4), "peak": round(mad_peak / 1e12, 4),
+                    "unit": "TMAC/s (v_mad_u64_u32)", "frac": round(a / mad_peak, 4),
+                    "algorithmic": "%.0f products per element (log2(n)/2 twiddles + 1 scaling) x 136 MAC" % ntt_prods,
+                    "valu_pmc": ntt_insts}
             for k in res_ntt:
                 res_ntt[k]["roofline"]["traffic"] = ntt_traffic
                 res_ntt[k]["roofline"]["traffic_note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, "

@@ -15,7 +15,11 @@ for p in paths:
         if "jf::" not in k:
             continue
         acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
-out = {"unit": "mean per launch", "kernels": {}}
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+import bench  # noqa: E402  (kernel_source_sha: ties this profile to the kernel sources it was taken on)
+
+out = {"unit": "mean per launch", "git_head": __import__("os").environ.get("JF_GIT_HEAD", ""),
+       "kernel_source_sha": bench.kernel_source_sha(), "kernels": {}}
 for k, cs in sorted(acc.items()):
     d = {c: sum(v) / len(v) for c, v in cs.items()}
     d["launches"] = max(len(v) for v in cs.values())
