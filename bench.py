@@ -633,11 +633,13 @@ def main():
                     "int64_class_insts_per_launch": d.get("SQ_INSTS_VALU_INT64"),
                     "mad_issue_cycles_frac": round(d.get("SQ_INSTS_VALU_INT64", 0.0) * 4.0 / (cyc * 1024.0), 3),
                     "wait_inst_any_frac_of_wave_cycles": d.get("frac_of_wave_cycles:SQ_WAIT_INST_ANY"),
-                    "valu_issue_frac": round(d["SQ_INSTS_VALU"] / cyc / 256.0, 3),
-                    "valu_issue_note": "wave-instructions per shader cycle over the chip / 256 (1024 SIMDs, one wave64 "
-                                       "instruction per 4 cycles each): how close the kernel is to the VALU issue limit; "
-                                       "executed_macs counts the v_mad_u64_u32 the kernel issues (29-bit limbs: 171 per "
-                                       "product + 9 v_mul_lo) against the 136-per-product convention of `algorithmic`",
+                    "simd_busy_frac": round((d.get("SQ_INSTS_VALU_INT64", 0.0) * 4.0 + (d["SQ_INSTS_VALU"] - d.get(
+                        "SQ_INSTS_VALU_INT64", 0.0)) * 2.0) / (cyc * 1024.0), 3),
+                    "simd_busy_note": "share of all SIMD cycles (1024 SIMDs x shader cycles) that the issued VALU instructions "
+                                      "occupy: a wave64 v_mad_u64_u32 / 64-bit shift holds its SIMD for 4 cycles, the 32-bit "
+                                      "adds / masks / moves for 2 (scripts/ubench/valu_rate.hip); executed_macs counts the "
+                                      "64-bit-class instructions the kernel issues (29-bit limbs: 171 v_mad_u64_u32 + 18 "
+                                      "64-bit shifts per product) against the 136-per-product convention of `algorithmic`",
                 }
         # second wall of this kernel: every mixed addition gathers one random 64-byte table point.  jfhip_probe(4, GiB)
         # measures the device's random 64-byte gather rate over a table of the same size, nothing else running.
