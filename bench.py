@@ -633,13 +633,19 @@ def main():
                     "int64_class_insts_per_launch": d.get("SQ_INSTS_VALU_INT64"),
                     "mad_issue_cycles_frac": round(d.get("SQ_INSTS_VALU_INT64", 0.0) * 4.0 / (cyc * 1024.0), 3),
                     "wait_inst_any_frac_of_wave_cycles": d.get("frac_of_wave_cycles:SQ_WAIT_INST_ANY"),
-                    "simd_busy_frac": round((d.get("SQ_INSTS_VALU_INT64", 0.0) * 4.0 + (d["SQ_INSTS_VALU"] - d.get(
-                        "SQ_INSTS_VALU_INT64", 0.0)) * 2.0) / (cyc * 1024.0), 3),
+                    "simd_busy_frac_range": [
+                        round(((d.get("SQ_INSTS_VALU_INT64", 0.0) + d.get("SQ_INSTS_VALU_INT32", 0.0)) * 4.0 + (
+                            d["SQ_INSTS_VALU"] - d.get("SQ_INSTS_VALU_INT64", 0.0) - d.get("SQ_INSTS_VALU_INT32", 0.0)) * 2.0) / (
+                                cyc * 1024.0), 3),
+                        round(d["SQ_INSTS_VALU"] * 4.0 / (cyc * 1024.0), 3)],
                     "simd_busy_note": "share of all SIMD cycles (1024 SIMDs x shader cycles) that the issued VALU instructions "
-                                      "occupy: a wave64 v_mad_u64_u32 / 64-bit shift holds its SIMD for 4 cycles, the 32-bit "
-                                      "adds / masks / moves for 2 (scripts/ubench/valu_rate.hip); executed_macs counts the "
-                                      "64-bit-class instructions the kernel issues (29-bit limbs: 171 v_mad_u64_u32 + 18 "
-                                      "64-bit shifts per product) against the 136-per-product convention of `algorithmic`",
+                                      "occupy: a wave64 v_mad_u64_u32 / 64-bit shift / 32-bit multiply / carry add holds its "
+                                      "SIMD for 4+ cycles, v_add_u32 / v_and / v_mov / 32-bit shifts for 2 "
+                                      "(scripts/ubench/valu_rate.hip, profiles/r03_valu_rate.txt); lower end: only the "
+                                      "INT64 + INT32 counter classes at 4, upper end: every instruction at 4.  "
+                                      "executed_macs counts the 64-bit-class instructions the kernel issues (29-bit limbs: 171 "
+                                      "v_mad_u64_u32 + 18 64-bit shifts per product) against the 136-per-product convention "
+                                      "of `algorithmic`",
                 }
         # second wall of this kernel: every mixed addition gathers one random 64-byte table point.  jfhip_probe(4, GiB)
         # measures the device's random 64-byte gather rate over a table of the same size, nothing else running.
@@ -652,7 +658,10 @@ def main():
                 "achieved": round(gathers / (acc_ms * 1e-3) / 1e9, 3), "peak": round(gather_peak / 1e9, 3),
                 "unit": "G gathers/s", "frac": round(gathers / (acc_ms * 1e-3) / gather_peak, 4),
                 "peak_source": "gather-only micro-benchmark on this device over a %d GiB table (5.5e10/s at 1 GiB, "
-                               "1.35e10/s at 12 GiB measured: TLB / fabric reach, not HBM bandwidth)" % table_gib}
+                               "1.35e10/s at 12 GiB measured: per-XCD translation reach, not HBM bandwidth)" % table_gib,
+                "note": "a rate that coincides with the kernel's, not a bound on it: with every gather redirected into one "
+                        "1 GiB window the same launch takes 14.63 instead of 14.80-14.85 ms "
+                        "(profiles/r03_slabtest_accumulate.log, DESIGN.md 3.2); the kernel is VALU-issue-bound"}
         except Exception as e:  # reporting only
             out["roofline"]["gather_view"] = {"error": repr(e)}
         out["phases_ms"] = phases
