@@ -567,10 +567,25 @@ JF_DEV void next_bucket(const uint32_t* __restrict__ off, uint32_t B, uint32_t p
 // inside a slice) that covers its whole bucket is final and goes to buckets[b]; a run cut
 // by a slice boundary goes to partA[t] (it contains the slice's first entry) or partB[t]
 // (it does not) and is stitched by k_msm_fixup.
+// Slice length of a call.  The host sizes T slices (one per lane) for the most entries the call can have, n x windows; how
+// many entries exist -- the non-zero digits -- is known on the device only (off[B] after the sort).  Every kernel after the
+// sort derives the SAME length from off[B] and T, so that with sparse scalars (witness values of a few bits fill one or two
+// of the 12-16 windows) all T lanes still get an equal share instead of the first few getting full-length slices.
+// lmin (the host's length capped at 32) keeps slices from becoming so short that one heavy bucket (all-equal scalars: n
+// entries in one bucket) spans tens of thousands of them for the fix-up's one workgroup per such bucket.
+struct SliceCfg {
+    uint32_t T;      // slices the workspace holds
+    uint32_t lmin;   // shortest slice
+};
+JF_DEV uint32_t msm_slice_len(uint32_t total, SliceCfg sc) {
+    const uint32_t l = (uint32_t)(((uint64_t)total + sc.T - 1) / sc.T);
+    return l < sc.lmin ? sc.lmin : l;
+}
+
 template <class Cv>
 __global__ __launch_bounds__(128) void k_msm_accumulate(const uint32_t* __restrict__ sorted,
                                                         const uint32_t* __restrict__ off, uint32_t B,
-                                                        const uint32_t* __restrict__ table, uint32_t L,
+                                                        const uint32_t* __restrict__ table, SliceCfg T,
                                                         uint32_t* __restrict__ buckets, uint32_t* __restrict__ partA,
                                                         uint32_t* __restrict__ partB) {
     using Q = typename Cv::Fq;
@@ -578,6 +593,7 @@ __global__ __launch_bounds__(128) void k_msm_accumulate(const uint32_t* __restri
     constexpr int XZ = 4 * Q::N;  // limbs per XYZZ point
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t total = off[B];
+    const uint32_t L = msm_slice_len(total, T);
     const uint64_t start64 = (uint64_t)t * L;
     if (start64 >= total) return;
     const uint32_t start = (uint32_t)start64;
@@ -708,7 +724,7 @@ JF_COLD Rare29<Cv> xyzz29_add_rare(XYZZ29<Cv> acc, const uint32_t* __restrict__ 
 template <class Cv, int OCC>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void k_msm_accumulate29(const uint32_t* __restrict__ sorted,
                                                           const uint32_t* __restrict__ off, uint32_t B,
-                                                          const uint32_t* __restrict__ table, uint32_t L,
+                                                          const uint32_t* __restrict__ table, SliceCfg T,
                                                           uint32_t* __restrict__ buckets, uint32_t* __restrict__ partA,
                                                           uint32_t* __restrict__ partB) {
     // buckets / partA / partB are RAW here: 4 L29 words per element, lazily reduced 29-bit limbs, all zero = identity.
@@ -721,6 +737,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     constexpr int XZ = 4 * F::L;
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t total = off[B];
+    const uint32_t L = msm_slice_len(total, T);
     const uint64_t start64 = (uint64_t)t * L;
     if (start64 >= total) return;
     const uint32_t start = (uint32_t)start64;
@@ -936,7 +953,7 @@ constexpr uint32_t HEAVY_SPAN = 48;
 // partA / partB: what the accumulation wrote; buckets: written here for the spanning buckets only, in the same
 // representation -- k_msm_bucket_fold takes every other bucket from the accumulation's own array.
 template <class Cv, bool RAW>
-__global__ __launch_bounds__(128) void k_msm_fixup(const uint32_t* __restrict__ off, uint32_t B, uint32_t L,
+__global__ __launch_bounds__(128) void k_msm_fixup(const uint32_t* __restrict__ off, uint32_t B, SliceCfg T,
                                                    const uint32_t* __restrict__ partA,
                                                    const uint32_t* __restrict__ partB,
                                                    uint32_t* __restrict__ buckets, uint32_t* __restrict__ heavy) {
@@ -945,6 +962,7 @@ __global__ __launch_bounds__(128) void k_msm_fixup(const uint32_t* __restrict__ 
     if (b >= B) return;
     uint32_t s = off[b], e = off[b + 1];
     if (e <= s) return;
+    const uint32_t L = msm_slice_len(off[B], T);
     uint32_t t1 = s / L, t2 = (e - 1) / L;
     if (t1 == t2) return;
     if (t2 - t1 > HEAVY_SPAN) {
@@ -959,9 +977,71 @@ __global__ __launch_bounds__(128) void k_msm_fixup(const uint32_t* __restrict__ 
     G::store(buckets, b, acc);
 }
 
-// one workgroup per queued bucket: lanes take the bucket's slices round-robin, then an LDS tree
+// Queued (heavy) buckets, two launches.  A bucket with all-equal or small-valued scalars holds up to n entries: tens of
+// thousands of slices once the slices are short (msm_slice_len), too many for one workgroup's 256 lanes to add up in
+// sequence (3.6 ms for a 2^22-entry bucket of BLS12-381).  k_msm_fixup_heavy_chunks cuts a bucket's full slices
+// t1 + 1 .. t2 into chunks of HEAVY_CHUNK, one workgroup per chunk (dealt round-robin over the grid), and leaves the chunk's sum IN PLACE in partA at the chunk's first slice -- the slices of a
+// chunk belong to this bucket alone and are read only by the workgroup that owns the chunk, before it writes.
+// k_msm_fixup_heavy then adds the bucket's first piece and its chunk sums, one workgroup per bucket.
+constexpr uint32_t HEAVY_CHUNK = 1024;
+template <class G>
+JF_DEV typename G::T heavy_block_sum(uint32_t* sh, typename G::T acc) {   // sum over the 256 lanes, valid in lane 0
+    G::store(sh, threadIdx.x, acc);
+    __syncthreads();
+    for (uint32_t w = 128; w > 0; w >>= 1) {
+        if (threadIdx.x < w) {
+            typename G::T q = G::load(sh, threadIdx.x + w);
+            G::add(acc, q);
+            G::store(sh, threadIdx.x, acc);
+        }
+        __syncthreads();
+    }
+    return acc;
+}
 template <class Cv, bool RAW>
-__global__ __launch_bounds__(256) void k_msm_fixup_heavy(const uint32_t* __restrict__ off, uint32_t L,
+__global__ __launch_bounds__(256) void k_msm_fixup_heavy_chunks(const uint32_t* __restrict__ off, uint32_t B, SliceCfg T,
+                                                                uint32_t* __restrict__ partA,
+                                                                const uint32_t* __restrict__ heavy) {
+    using G = Rep<Cv, RAW>;
+    __shared__ uint32_t sh[256 * G::W];
+    __shared__ uint32_t q_t1[256], q_t2[256];
+    const uint32_t count = heavy[0];
+    const uint32_t L = msm_slice_len(off[B], T);
+    uint32_t qbase = 0;
+    for (uint32_t base = 0; base < count; base += 256u) {
+        __syncthreads();
+        if (base + threadIdx.x < count) {
+            const uint32_t b = heavy[1 + base + threadIdx.x];
+            q_t1[threadIdx.x] = off[b] / L;
+            q_t2[threadIdx.x] = (off[b + 1] - 1) / L;
+        }
+        __syncthreads();
+        const uint32_t m = count - base < 256u ? count - base : 256u;
+        for (uint32_t j = 0; j < m; j++) {
+            const uint32_t t1 = q_t1[j], t2 = q_t2[j];
+            const uint32_t chunks = (t2 - t1 + HEAVY_CHUNK - 1) / HEAVY_CHUNK;   // slices t1 + 1 .. t2
+            if (chunks <= 1) continue;   // a single chunk is summed by k_msm_fixup_heavy directly
+            // chunks are numbered through the whole queue (every workgroup keeps the same running count) and dealt
+            // round-robin: neighbouring buckets must not land on the same few workgroups
+            uint32_t c = (blockIdx.x + gridDim.x - qbase % gridDim.x) % gridDim.x;
+            qbase += chunks;
+            for (; c < chunks; c += gridDim.x) {
+                const uint32_t first = t1 + 1 + c * HEAVY_CHUNK;
+                const uint32_t last = first + HEAVY_CHUNK - 1 < t2 ? first + HEAVY_CHUNK - 1 : t2;
+                typename G::T acc = G::identity();
+                for (uint32_t t = first + threadIdx.x; t <= last; t += 256u) {
+                    typename G::T q = G::load(partA, t);
+                    G::add(acc, q);
+                }
+                acc = heavy_block_sum<G>(sh, acc);   // every lane's loads are done at its first barrier
+                if (threadIdx.x == 0) G::store(partA, first, acc);
+            }
+        }
+    }
+}
+
+template <class Cv, bool RAW>
+__global__ __launch_bounds__(256) void k_msm_fixup_heavy(const uint32_t* __restrict__ off, uint32_t B, SliceCfg T,
                                                          const uint32_t* __restrict__ partA,
                                                          const uint32_t* __restrict__ partB,
                                                          uint32_t* __restrict__ buckets,
@@ -969,27 +1049,28 @@ __global__ __launch_bounds__(256) void k_msm_fixup_heavy(const uint32_t* __restr
     using G = Rep<Cv, RAW>;
     __shared__ uint32_t sh[256 * G::W];
     const uint32_t count = heavy[0];
+    const uint32_t L = msm_slice_len(off[B], T);
     for (uint32_t h = blockIdx.x; h < count; h += gridDim.x) {
         const uint32_t b = heavy[1 + h];
         const uint32_t s = off[b], e = off[b + 1];
         const uint32_t t1 = s / L, t2 = (e - 1) / L;
+        const uint32_t chunks = (t2 - t1 + HEAVY_CHUNK - 1) / HEAVY_CHUNK;
         typename G::T acc = G::identity();
         if (threadIdx.x == 0) acc = G::load((s % L == 0) ? partA : partB, t1);
-        for (uint32_t t = t1 + 1 + threadIdx.x; t <= t2; t += 256u) {
-            typename G::T q = G::load(partA, t);
-            G::add(acc, q);
-        }
-        G::store(sh, threadIdx.x, acc);
-        __syncthreads();
-        for (uint32_t w = 128; w > 0; w >>= 1) {
-            if (threadIdx.x < w) {
-                typename G::T q = G::load(sh, threadIdx.x + w);
+        if (chunks <= 1) {
+            for (uint32_t t = t1 + 1 + threadIdx.x; t <= t2; t += 256u) {
+                typename G::T q = G::load(partA, t);
                 G::add(acc, q);
-                G::store(sh, threadIdx.x, acc);
             }
-            __syncthreads();
+        } else {
+            for (uint32_t c = threadIdx.x; c < chunks; c += 256u) {   // chunk sums left in place by k_msm_fixup_heavy_chunks
+                typename G::T q = G::load(partA, t1 + 1 + c * HEAVY_CHUNK);
+                G::add(acc, q);
+            }
         }
+        acc = heavy_block_sum<G>(sh, acc);
         if (threadIdx.x == 0) G::store(buckets, b, acc);
+        __syncthreads();
     }
 }
 
@@ -1021,11 +1102,12 @@ JF_DEV typename Rep<Cv, RAW>::T rep_mul_small(const typename Rep<Cv, RAW>::T& p,
 template <class Cv, bool RAW>
 __global__ __launch_bounds__(64) void k_msm_bucket_fold(const uint32_t* __restrict__ fixed,
                                                         const uint32_t* __restrict__ acc_buckets,
-                                                        const uint32_t* __restrict__ off, uint32_t L, uint32_t B,
+                                                        const uint32_t* __restrict__ off, SliceCfg T, uint32_t B,
                                                         uint32_t Bper, uint32_t g, uint32_t* __restrict__ out) {
     using G = Rep<Cv, RAW>;
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if ((uint64_t)t * g >= B) return;
+    const uint32_t L = msm_slice_len(off[B], T);
     uint32_t lo = t * g, hi = (lo + g < B) ? lo + g : B;
     typename G::T run = G::identity(), sum = G::identity();
     for (uint32_t j = hi; j-- > lo;) {
@@ -1631,6 +1713,9 @@ static int32_t msm_multi_t(const jfhip_srs* srs, MsmBatch mb, uint32_t* d_out_xy
     size_t L = (total_max + lanes * rounds - 1) / (lanes * rounds);
     if (L < 16) L = 16;
     const size_t T = (total_max + L - 1) / L;
+    // the kernels derive the slice length from off[B]; JFHIP_MSM_FIXED_SLICE=1 pins it to the host's L (rounds 1-2, A/B)
+    static const bool fixed_slice = getenv("JFHIP_MSM_FIXED_SLICE") && getenv("JFHIP_MSM_FIXED_SLICE")[0] == '1';
+    const SliceCfg scfg{(uint32_t)T, (uint32_t)(fixed_slice || L < 32 ? L : 32)};
     DigitPlan pl;
     pl.c = c;
     pl.W = W;
@@ -1780,30 +1865,34 @@ static int32_t msm_multi_t(const jfhip_srs* srs, MsmBatch mb, uint32_t* d_out_xy
         uint32_t* rawB = raw + ((size_t)B + T) * XR;
         JF_HIP(hipMemsetAsync(raw, 0, (size_t)B * XR * 4, st->s));  // untouched buckets are the identity
         hipLaunchKernelGGL(kern, dim3((unsigned)((T + 127) / 128)), dim3(128), 0, st->s, st->sorted.as<uint32_t>(), offs,
-                           B, srs->table, (uint32_t)L, raw, rawA, rawB);
+                           B, srs->table, scfg, raw, rawA, rawB);
         pt.mark();
         // the runs stay in the accumulation's raw form through the fix-up, the fold and the sum tree
-        hipLaunchKernelGGL((k_msm_fixup<Cv, true>), dim3((B + 127) / 128), dim3(128), 0, st->s, offs, B, (uint32_t)L, rawA,
+        hipLaunchKernelGGL((k_msm_fixup<Cv, true>), dim3((B + 127) / 128), dim3(128), 0, st->s, offs, B, scfg, rawA,
                            rawB, buckets, st->heavy.as<uint32_t>());
-        hipLaunchKernelGGL((k_msm_fixup_heavy<Cv, true>), dim3(1024), dim3(256), 0, st->s, offs, (uint32_t)L, rawA, rawB,
+        hipLaunchKernelGGL((k_msm_fixup_heavy_chunks<Cv, true>), dim3(1024), dim3(256), 0, st->s, offs, B, scfg, rawA,
+                           st->heavy.as<uint32_t>());
+        hipLaunchKernelGGL((k_msm_fixup_heavy<Cv, true>), dim3(1024), dim3(256), 0, st->s, offs, B, scfg, rawA, rawB,
                            buckets, st->heavy.as<uint32_t>());
         pt.mark();
         hipLaunchKernelGGL((k_msm_bucket_fold<Cv, true>), dim3((unsigned)((Tf + 63) / 64)), dim3(64), 0, st->s, buckets, raw,
-                           offs, (uint32_t)L, B, Bper, g, fold);
+                           offs, scfg, B, Bper, g, fold);
     } else {
         JF_HIP(hipMemsetAsync(buckets, 0, (size_t)B * XZ * 4, st->s));
         hipLaunchKernelGGL((k_msm_accumulate<Cv>), dim3((unsigned)((T + 127) / 128)), dim3(128), 0, st->s,
-                           st->sorted.as<uint32_t>(), offs, B, srs->table, (uint32_t)L, buckets,
+                           st->sorted.as<uint32_t>(), offs, B, srs->table, scfg, buckets,
                            st->partA.as<uint32_t>(), st->partB.as<uint32_t>());
         pt.mark();
-        hipLaunchKernelGGL((k_msm_fixup<Cv, false>), dim3((B + 127) / 128), dim3(128), 0, st->s, offs, B, (uint32_t)L,
+        hipLaunchKernelGGL((k_msm_fixup<Cv, false>), dim3((B + 127) / 128), dim3(128), 0, st->s, offs, B, scfg,
                            st->partA.as<uint32_t>(), st->partB.as<uint32_t>(), buckets, st->heavy.as<uint32_t>());
-        hipLaunchKernelGGL((k_msm_fixup_heavy<Cv, false>), dim3(1024), dim3(256), 0, st->s, offs, (uint32_t)L,
+        hipLaunchKernelGGL((k_msm_fixup_heavy_chunks<Cv, false>), dim3(1024), dim3(256), 0, st->s, offs, B, scfg,
+                           st->partA.as<uint32_t>(), st->heavy.as<uint32_t>());
+        hipLaunchKernelGGL((k_msm_fixup_heavy<Cv, false>), dim3(1024), dim3(256), 0, st->s, offs, B, scfg,
                            st->partA.as<uint32_t>(), st->partB.as<uint32_t>(), buckets, st->heavy.as<uint32_t>());
         pt.mark();
         // partA is free again after the fix-up
         hipLaunchKernelGGL((k_msm_bucket_fold<Cv, false>), dim3((unsigned)((Tf + 63) / 64)), dim3(64), 0, st->s, buckets,
-                           buckets, offs, (uint32_t)L, B, Bper, g, fold);
+                           buckets, offs, scfg, B, Bper, g, fold);
     }
     JF_HIP(hipGetLastError());
     pt.mark();

@@ -371,3 +371,52 @@ def test_msm_small_on_host_points(hip, setup, n):
         return
     exp = C.msm(cv.curve_id, pts, sc)
     assert (got == exp).all() and inf == (not exp.any())
+
+
+@pytest.mark.parametrize("cv", CURVES, ids=lambda c: c.name)
+def test_msm_small_valued_scalars_fill_the_chip(hip, cv):
+    """Witness-like scalars (the bench circuits' wires hold counters, booleans and constants: a few bits each) give non-zero
+    digits in one or two of the ~15 windows, so the sorted entry list is a small fraction of n x windows.  The kernels
+    after the sort derive the slice length from the entry count the sort leaves on the device (msm_slice_len), so every
+    lane still gets an equal share: same points as the oracle, and a small-valued MSM must be much cheaper than a dense
+    one of the same length (it took the dense time before: the first few lanes got full-length slices)."""
+    import time
+
+    import torch
+
+    n = (1 << 18) + 3
+    beta = mont_arr(cv.fr, [0x5EED0042])[0]
+    srs = hip.Srs.gen_for_testing(cv.curve_id, beta, pt_arr(cv, cv.g), n)
+    bases = srs.read(0, n)
+    dense = rand_fr_mont(cv, n, 91)
+    counter = mont_arr(cv.fr, list(range(n)))                        # w_i = i: two windows
+    ones = np.repeat(mont_arr(cv.fr, [1]), n, axis=0)                # one bucket holds everything (heavy fix-up)
+    bools = mont_arr(cv.fr, [0, 1])[(np.arange(n) * 7 // 3) % 2]      # half the entries vanish
+    neg_small = mont_arr(cv.fr, [cv.fr.p - 1 - (i % 1000) for i in range(n)])   # -1 - k: small after the sign trick? (dense digits)
+    for sc in (counter, ones, bools, neg_small):
+        got, inf = hip.msm(srs, np.ascontiguousarray(sc))
+        exp = C.msm(cv.curve_id, bases, np.ascontiguousarray(sc))
+        assert (got == exp).all() and inf == (0 if exp.any() else 1)
+
+    st = hip.Stream()
+    out = torch.zeros(256, dtype=torch.uint8, device="cuda")
+
+    def timed(sc_np):
+        sc = torch.from_numpy(np.ascontiguousarray(sc_np).view(np.int64)).cuda()
+        ts = []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            hip.msm_device(srs, sc.data_ptr(), n, out.data_ptr(), stream=st)
+            st.sync()
+            ts.append(time.perf_counter() - t0)
+        return min(ts[1:])
+
+    srs.free()
+    # timing property at the size of a prover's commitment (below ~2^18 both are bound by the latency of the tail)
+    n = (1 << 20) + 3
+    srs = hip.Srs.gen_for_testing(cv.curve_id, beta, pt_arr(cv, cv.g), n)
+    t_dense = timed(rand_fr_mont(cv, n, 92))
+    t_counter = timed(mont_arr(cv.fr, list(range(n))))
+    assert t_counter < 0.75 * t_dense, (t_counter, t_dense)
+    srs.free()
