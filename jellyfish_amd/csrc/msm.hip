@@ -156,31 +156,6 @@ __global__ __launch_bounds__(256) void k_msm_coarse(MsmBatch mb, DigitPlan pl, u
     }
 }
 
-// exclusive scan of the coarse counts (<= 1024) -> cbase[0..nb], cursors = cbase; off[B] = total
-__global__ __launch_bounds__(1024) void k_msm_coarse_scan(const uint32_t* __restrict__ ccount, uint32_t nb,
-                                                          uint32_t* __restrict__ cbase, uint32_t* __restrict__ cursor,
-                                                          uint32_t* __restrict__ off_total) {
-    __shared__ uint32_t sh[1024];
-    uint32_t v = threadIdx.x < nb ? ccount[threadIdx.x] : 0u;
-    sh[threadIdx.x] = v;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
-        uint32_t t = (threadIdx.x >= (unsigned)d) ? sh[threadIdx.x - d] : 0u;
-        __syncthreads();
-        sh[threadIdx.x] += t;
-        __syncthreads();
-    }
-    uint32_t excl = sh[threadIdx.x] - v;
-    if (threadIdx.x < nb) {
-        cbase[threadIdx.x] = excl;
-        cursor[threadIdx.x] = excl;
-    }
-    if (threadIdx.x == 1023) {
-        cbase[nb] = sh[1023];
-        *off_total = sh[1023];
-    }
-}
-
 // ---- refinement levels: equal-sized chunks of the entry array, any segment skew ----------------
 //
 // Input entries are grouped by the key bits above `shift + bits` (segments given by segbase).
@@ -571,8 +546,7 @@ JF_DEV void next_bucket(const uint32_t* __restrict__ off, uint32_t B, uint32_t p
 // many entries exist -- the non-zero digits -- is known on the device only (off[B] after the sort).  Every kernel after the
 // sort derives the SAME length from off[B] and T, so that with sparse scalars (witness values of a few bits fill one or two
 // of the 12-16 windows) all T lanes still get an equal share instead of the first few getting full-length slices.
-// lmin (the host's length capped at 32) keeps slices from becoming so short that one heavy bucket (all-equal scalars: n
-// entries in one bucket) spans tens of thousands of them for the fix-up's one workgroup per such bucket.
+// lmin (16, or JFHIP_MSM_MIN_SLICE) bounds the per-slice overhead (a bucket search and two partial sums per lane).
 struct SliceCfg {
     uint32_t T;      // slices the workspace holds
     uint32_t lmin;   // shortest slice
@@ -1715,7 +1689,9 @@ static int32_t msm_multi_t(const jfhip_srs* srs, MsmBatch mb, uint32_t* d_out_xy
     const size_t T = (total_max + L - 1) / L;
     // the kernels derive the slice length from off[B]; JFHIP_MSM_FIXED_SLICE=1 pins it to the host's L (rounds 1-2, A/B)
     static const bool fixed_slice = getenv("JFHIP_MSM_FIXED_SLICE") && getenv("JFHIP_MSM_FIXED_SLICE")[0] == '1';
-    const SliceCfg scfg{(uint32_t)T, (uint32_t)(fixed_slice || L < 32 ? L : 32)};
+    static const int env_min_slice = getenv("JFHIP_MSM_MIN_SLICE") ? atoi(getenv("JFHIP_MSM_MIN_SLICE")) : 0;
+    const size_t min_slice = env_min_slice >= 16 && env_min_slice <= 256 ? (size_t)env_min_slice : 16;   // 16 / 32 / 64 measured
+    const SliceCfg scfg{(uint32_t)T, (uint32_t)(fixed_slice || L < min_slice ? L : min_slice)};
     DigitPlan pl;
     pl.c = c;
     pl.W = W;
