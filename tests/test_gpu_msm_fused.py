@@ -94,7 +94,7 @@ def test_fused_batch_equals_per_polynomial_path_at_2_16(hip, cv):
         torch.cuda.synchronize()
         single = out.cpu().numpy()[:16 * cv.fq.limbs64].copy().view(np.uint64)
         assert (single == pts[i]).all(), i
-    _check(cv, host, polys[:2], pts[:2], inf[:2])
+    _check(cv, host, polys, pts, inf)   # member 3 has all-equal coefficients: its buckets go through the chunked heavy fix-up
     srs.free()
 
 
