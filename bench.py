@@ -187,12 +187,34 @@ def real_prove_section(L, torch, dist, world, log_g=20):
         ts_all = timed(3)
     finally:
         JP.SKIP_ZERO_POLYS = True
+    # third mode (one GPU): the round-1 commitments as MSMs over the witness VALUES on the Lagrange-basis form of the commit
+    # key (ProvingKey.keep_lagrange_commit_key: one group DFT of the SRS at set-up, a second window table) -- same group
+    # elements, same proof bytes; what it saves depends on how small the witness values are (this circuit: counters,
+    # ones and zeros), a dense witness gains nothing
+    ts_lag, lag_same, lag_setup_s = None, None, None
+    if world == 1:
+        t0 = time.perf_counter()
+        pk.keep_lagrange_commit_key()
+        torch.cuda.synchronize()
+        lag_setup_s = time.perf_counter() - t0
+        lag_same = JP.PlonkKzgSnark.prove(H.test_rng(), cs, pk, witness_mont=wit).serialize_compressed() == \
+            JP.PlonkKzgSnark.prove(H.test_rng(), cs, pk.drop_lagrange_commit_key(), witness_mont=wit).serialize_compressed()
+        pk.keep_lagrange_commit_key()
+        JP.PlonkKzgSnark.prove(rng, cs, pk, witness_mont=wit)
+        ts_lag = timed()
+        pk.drop_lagrange_commit_key()
     # second mode: the proving key keeps its 18 selector / sigma coset evaluations (this rank's slice) in HBM
     rank = dist.get_rank() if world > 1 else 0
     pk.keep_coset_evals(rank=rank, world=world)
     kept_bytes = pk.coset_evals_bytes()
     JP.PlonkKzgSnark.prove(rng, cs, pk, witness_mont=wit, sharded=world > 1)
     ts_kept = timed()
+    ts_both = None
+    if world == 1:      # both options together
+        pk.keep_lagrange_commit_key()
+        JP.PlonkKzgSnark.prove(rng, cs, pk, witness_mont=wit)
+        ts_both = timed()
+        pk.drop_lagrange_commit_key()
     m = pk.quot_domain_size()
     coset_sharded = JP.coset_sharding_applies(n, m, world)
     sec = {"workload": "PlonkKzgSnark::prove, TurboPlonk BN254, gen_circuit_for_bench(2^%d gates), StandardTranscript, "
@@ -218,6 +240,14 @@ def real_prove_section(L, torch, dist, world, log_g=20):
                                       "evaluations in HBM (%.2f GiB per rank), so a proof runs 7 coset NTTs instead of "
                                       "the reference's 25 (prover.rs:534-544 recomputes them per proof); same proof "
                                       "bytes.  'ms' recomputes all 25 like the reference" % (kept_bytes / 2**30),
+           "ms_pk_coset_evals_resident_and_lagrange_commits": round(float(np.median(ts_both)), 3) if ts_both else None,
+           "ms_lagrange_round1_commits": round(float(np.median(ts_lag)), 3) if ts_lag else None,
+           "lagrange_round1_commits": "third timing (one GPU): ProvingKey.keep_lagrange_commit_key() -- the 5 wire commitments "
+                                      "are MSMs over the witness values + blinders on [L_i(beta)]g (jfhip_srs_lagrange, %s s "
+                                      "at set-up) instead of over the iFFT's coefficients; proof bytes equal: %s.  The "
+                                      "gain is this circuit's (wires hold counters, ones, zeros); 'ms' commits coefficient "
+                                      "vectors like the reference (prover.rs:77-91)"
+                                      % ("%.2f" % lag_setup_s if lag_setup_s is not None else "-", lag_same),
            "ns_per_gate": round(float(np.median(ts)) * 1e6 / (1 << log_g), 2),
            "includes": "witness upload (32 B x num_vars), all device work, host Merlin transcript + RNG, read-back of "
                        "13 commitments and 10 evaluations",
@@ -346,6 +376,27 @@ def batch_prove_section(L, torch, dist, world, rank, stream, log_g):
     run()
     rounds = dict(JP.PROFILE)
     JP.PROFILE = None
+    # third timing (one GPU): round-1 / round-1.5 commitments from evaluations on the Lagrange-basis commit key
+    ts_lag, lag_same, lag_setup_s, lag_rounds = None, None, None, None
+    if world == 1:
+        t0 = time.perf_counter()
+        pk.keep_lagrange_commit_key()
+        torch.cuda.synchronize()
+        lag_setup_s = time.perf_counter() - t0
+        rng = H.test_rng()
+        lag_same = run().serialize_compressed() == first
+        ts_lag = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run()
+            torch.cuda.synchronize()
+            ts_lag.append((time.perf_counter() - t0) * 1e3)
+        JP.PROFILE = {}
+        run()
+        lag_rounds = {k: v for k, v in JP.PROFILE.items() if k in ("r1_commit", "r1p_commit")}
+        JP.PROFILE = None
+        pk.drop_lagrange_commit_key()
     # second timing: the 24 proving-key polynomials' coset evaluations resident in HBM (same proof bytes)
     pk.keep_coset_evals()
     kept_bytes = pk.coset_evals_bytes()
@@ -363,6 +414,18 @@ def batch_prove_section(L, torch, dist, world, rank, stream, log_g):
         if world > 1:
             dt = max_over_ranks(torch, dist, dt)
         ts_res.append(dt * 1e3)
+    ts_both = None
+    if world == 1:      # both options together
+        pk.keep_lagrange_commit_key()
+        run()
+        ts_both = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run()
+            torch.cuda.synchronize()
+            ts_both.append((time.perf_counter() - t0) * 1e3)
+        pk.drop_lagrange_commit_key()
     sec = {"workload": "PlonkKzgSnark::batch_prove, %d UltraPlonk (Plookup, range_bit_len 8) BLS12-381 bench circuits of "
                        "2^%d gates, one per GPU -> one BatchProof; StandardTranscript, blinding from test_rng; per circuit "
                        "11 iNTT(n) + 35 coset NTT(8n) + sorted-vector merge + 2 grand products + Plookup quotient + coset "
@@ -379,6 +442,14 @@ def batch_prove_section(L, torch, dist, world, rank, stream, log_g):
                                       "recomputes them per proof); proof bytes equal to the first timing's: %s.  'ms' "
                                       "recomputes all 35 like the reference"
                                       % (pk.selectors.shape[0], pk.sigmas.shape[0], kept_bytes / 2**30, same),
+           "ms_pk_coset_evals_resident_and_lagrange_commits": round(float(np.median(ts_both)), 3) if ts_both else None,
+           "ms_lagrange_round1_commits": round(float(np.median(ts_lag)), 3) if ts_lag else None,
+           "lagrange_round1_commits": "third timing (one GPU): ProvingKey.keep_lagrange_commit_key() -- the 6 wire and 2 sorted-"
+                                      "lookup commitments are MSMs over evaluations + blinders on [L_i(beta)]g "
+                                      "(jfhip_srs_lagrange, %s s at set-up) instead of over coefficients; commit rounds then "
+                                      "%s ms; proof bytes equal to the first timing's: %s.  The gain is this circuit's "
+                                      "(small witness values); 'ms' commits coefficient vectors like the reference"
+                                      % ("%.2f" % lag_setup_s if lag_setup_s is not None else "-", lag_rounds, lag_same),
            "includes": "witness upload, all device work, host Merlin transcript + RNG, commitment / evaluation read-backs",
            "setup_not_timed": {"circuit_build_s": round(build_s, 2), "srs_and_preprocess_s": round(setup_s, 2)},
            "proof_bytes": len(first), "first_proof_sha": hashlib.sha256(first).hexdigest()[:16],

@@ -98,6 +98,17 @@ int32_t jfhip_stream_wrap(void *hip_stream, jfhip_stream **out);
  * n == 0 is JFHIP_ERR_INVALID (reference :772-778 rejects supported_degree > len-1). */
 int32_t jfhip_srs_load(int32_t curve_id, const void *points, size_t n, size_t stride_bytes, int32_t window_bits,
                        jfhip_srs **out);
+/* Lagrange-basis commit key of a radix-2 domain, derived from a loaded (monomial) SRS: a NEW handle of n + blinders points,
+ * n = 2^log_n, holding [L_i(beta)]g for the Lagrange basis L_i of the domain {w^i} (the inverse group DFT of the first n
+ * points: L_i(X) = (1/n) sum_j w^(-ij) X^j) followed by V_k = [beta^(n+k)]g - [beta^k]g, k < blinders.  jfhip_msm* over
+ * (e_0 .. e_(n-1), b_0 .. b_(h)) on that handle is the commitment -- the same group element -- of the polynomial with
+ * evaluations e_i on the domain plus the prover's blinding (b_0 + .. + b_h X^h)(X^n - 1) (reference
+ * plonk/src/proof_system/prover.rs:457-466; wire polynomials :77-91, Plookup sorted polynomials :99-124): witness values
+ * are often a few bits wide where the coefficients after the iFFT (relation/src/constraint_system.rs:1422-1444) never
+ * are, and the bucket sort drops zero digits.  No counterpart in the reference (it commits coefficient vectors only).
+ * Needs srs to hold n + blinders points; costs one group DFT of size n (seconds at 2^22) and a second window table.
+ * Free with jfhip_srs_free. */
+int32_t jfhip_srs_lagrange(const jfhip_srs *srs, uint32_t log_n, uint32_t blinders, int32_t window_bits, jfhip_srs **out);
 /* Same, from n packed affine points already in device memory. */
 int32_t jfhip_srs_load_device(int32_t curve_id, const void *d_points_packed, size_t n, int32_t window_bits,
                               jfhip_srs **out);

@@ -459,6 +459,40 @@ int32_t jfhip_srs_load_device(int32_t curve_id, const void* d_points_packed, siz
     return JFHIP_OK;
 }
 
+int32_t jfhip_srs_lagrange(const jfhip_srs* srs, uint32_t log_n, uint32_t blinders, int32_t window_bits, jfhip_srs** out) {
+    if (!srs || !out) {
+        set_error("null argument");
+        return JFHIP_ERR_INVALID;
+    }
+    const uint32_t adicity = srs->curve == JFHIP_BN254 ? 28u : 32u;
+    if (log_n > adicity || log_n > 26 || blinders > 16) {
+        set_error("lagrange key: domain of 2^%u points / %u blinders unsupported", log_n, blinders);
+        return JFHIP_ERR_INVALID;
+    }
+    const size_t n = (size_t)1 << log_n;
+    if (srs->n < n + blinders) {
+        set_error("lagrange key: the SRS holds %zu points, a domain of %zu with %u blinders needs %zu", srs->n, n, blinders,
+                  n + blinders);
+        return JFHIP_ERR_INVALID;
+    }
+    JF_STREAM(st, nullptr);
+    std::lock_guard<std::mutex> lk(st->mu);
+    DevBuf packed;
+    JF_TRY(packed.ensure((n + blinders) * 2 * (size_t)fq_bytes(srs->curve)));
+    int32_t rc = srs_lagrange_points(srs, log_n, blinders, packed.as<uint32_t>(), st);
+    jfhip_srs* lag = nullptr;
+    if (rc == JFHIP_OK) rc = srs_alloc(srs->curve, n + blinders, window_bits, &lag);
+    if (rc == JFHIP_OK) rc = srs_build_table(lag, packed.as<uint32_t>(), st);
+    if (rc == JFHIP_OK && hipStreamSynchronize(st->s) != hipSuccess) rc = JFHIP_ERR_DEVICE;
+    packed.release();
+    if (rc != JFHIP_OK) {
+        if (lag) jfhip_srs_free(lag);
+        return rc;
+    }
+    *out = lag;
+    return JFHIP_OK;
+}
+
 int32_t jfhip_srs_load_serialized(int32_t curve_id, const uint8_t* bytes, size_t len, size_t n, int32_t compressed,
                                   int32_t validate, int32_t window_bits, jfhip_srs** out) {
     if (!bytes || !out) {

@@ -304,6 +304,8 @@ int32_t poly_divide_linear_noalloc(int32_t curve, const uint32_t* d_coeffs, size
                                    uint32_t* d_out, hipStream_t stream);
 int32_t witness_gather_device(const uint32_t* d_witness, size_t num_vars, const uint32_t* d_wire_variables, size_t count,
                               uint32_t* d_out, jfhip_stream* st);
+// n + blinders packed affine points: [L_i(beta)] g for the radix-2 domain of size n = 2^log_n, then S_(n+k) - S_k (ecntt.hip)
+int32_t srs_lagrange_points(const jfhip_srs* srs, uint32_t log_n, uint32_t blinders, uint32_t* d_packed, jfhip_stream* st);
 int32_t multi_open_rou_device(const jfhip_srs* srs, const uint32_t* d_coeffs, size_t ncoeffs, uint32_t log_dom,
                               size_t num_points, uint32_t* d_out, size_t rec_bytes, uint32_t log_M, jfhip_stream* st);
 int32_t plonk_lookup_sorted_device(const uint32_t* d_table, size_t n, const uint32_t* d_lookups, size_t n_lookups,

@@ -280,6 +280,85 @@ int32_t multi_open_rou_device(const jfhip_srs* srs, const uint32_t* d_coeffs, si
     return multi_open_rou_t<Bls381G1>(srs, d_coeffs, ncoeffs, log_dom, num_points, d_out, rec_bytes, log_M, st);
 }
 
+// ---- Lagrange-basis commit key -----------------------------------------------------------------------------------
+// G_i = [L_i(beta)] g, i < n = 2^log_n, with L_i the Lagrange basis of the radix-2 domain {w^i}: since
+// L_i(X) = (1 / n) sum_j w^(-ij) X^j, the points are the inverse group DFT of the monomial key S_j = [beta^j] g.  A
+// polynomial given by its evaluations e_i on the domain then commits as sum_i e_i G_i -- the same group element as the
+// monomial commitment of its coefficients -- and the prover's blinding (b_0 + b_1 X + ..)(X^n - 1) (prover.rs:457-466) adds
+// sum_k b_k V_k with V_k = S_(n+k) - S_k, appended after the n Lagrange points.  out: n + blinders packed affine points.
+template <class Cv>
+__global__ __launch_bounds__(256) void k_ec_fill_one(uint32_t count, uint32_t* __restrict__ out) {
+    using Fr = typename Cv::Fr;
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < count) fp_store<Fr>(out + (size_t)k * Fr::N, Fp<Fr>::one());
+}
+// V_k = S_(n+k) - S_k for k < blinders, written after the n transformed points
+template <class Cv>
+__global__ __launch_bounds__(64) void k_ec_vanishing_points(const uint32_t* __restrict__ table, int f29, uint32_t n,
+                                                            uint32_t blinders, uint32_t* __restrict__ data) {
+    using Q = typename Cv::Fq;
+    constexpr int PT = 2 * Q::N, XZ = 4 * Q::N;
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= blinders) return;
+    Affine<Cv> hi = affine_load<Cv>(table + (size_t)(n + k) * PT), lo = affine_load<Cv>(table + (size_t)k * PT);
+    if (f29) {
+        hi.x = fp_scale_down_r29<Q>(hi.x), hi.y = fp_scale_down_r29<Q>(hi.y);
+        lo.x = fp_scale_down_r29<Q>(lo.x), lo.y = fp_scale_down_r29<Q>(lo.y);
+    }
+    XYZZ<Cv> acc = hi.is_inf() ? XYZZ<Cv>::identity() : xyzz_from_affine<Cv>(hi);
+    if (!lo.is_inf()) {
+        lo.y = fp_neg<Q>(lo.y);
+        xyzz_add_affine<Cv>(acc, lo);
+    }
+    xyzz_store<Cv>(data + (size_t)(n + k) * XZ, acc);
+}
+// XYZZ -> packed affine points (identity = all zero), no flag word
+template <class Cv>
+__global__ __launch_bounds__(EC_BLOCK) void k_ec_to_packed(const uint32_t* __restrict__ in, uint32_t count,
+                                                           uint32_t* __restrict__ out) {
+    constexpr int PT = 2 * Cv::Fq::N, XZ = 4 * Cv::Fq::N;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    affine_store<Cv>(out + (size_t)i * PT, xyzz_to_affine<Cv>(xyzz_load<Cv>(in + (size_t)i * XZ)));
+}
+
+template <class Cv>
+static int32_t srs_lagrange_points_t(const jfhip_srs* srs, uint32_t log_n, uint32_t blinders, uint32_t* d_packed,
+                                     jfhip_stream* st) {
+    using Fr = typename Cv::Fr;
+    constexpr int XZ = 4 * Cv::Fq::N;
+    const uint32_t n = 1u << log_n;
+    const size_t total = (size_t)n + blinders;
+    ScopedBuf pts, tmp, tw, ones, par;
+    JF_TRY(pts.b.ensure(total * XZ * 4));
+    JF_TRY(tmp.b.ensure((size_t)n * XZ * 4));
+    JF_TRY(tw.b.ensure(((size_t)n / 2 + 1) * Fr::N * 4));
+    JF_TRY(ones.b.ensure((size_t)n * Fr::N * 4));
+    JF_TRY(par.b.ensure(Fr::N * 4));
+    uint32_t* P = pts.b.as<uint32_t>();
+    hipLaunchKernelGGL((k_ec_from_srs<Cv>), dim3((n + 255) / 256), dim3(256), 0, st->s, srs->table, (int)srs->f29, n, n, P);
+    JF_TRY(ec_ntt_t<Cv>(srs->curve, P, tmp.b.as<uint32_t>(), tw.b.as<uint32_t>(), log_n, 1, st));
+    // the 1 / n of the inverse transform
+    hipLaunchKernelGGL((k_ec_minv<Cv>), dim3(1), dim3(64), 0, st->s, log_n, par.b.as<uint32_t>());
+    hipLaunchKernelGGL((k_ec_fill_one<Cv>), dim3((n + 255) / 256), dim3(256), 0, st->s, n, ones.b.as<uint32_t>());
+    if (log_n)
+        hipLaunchKernelGGL((k_ec_scale<Cv>), dim3((n + EC_BLOCK - 1) / EC_BLOCK), dim3(EC_BLOCK), 0, st->s, P,
+                           ones.b.as<uint32_t>(), par.b.as<uint32_t>(), n);
+    if (blinders)
+        hipLaunchKernelGGL((k_ec_vanishing_points<Cv>), dim3((blinders + 63) / 64), dim3(64), 0, st->s, srs->table,
+                           (int)srs->f29, n, blinders, P);
+    hipLaunchKernelGGL((k_ec_to_packed<Cv>), dim3((unsigned)((total + EC_BLOCK - 1) / EC_BLOCK)), dim3(EC_BLOCK), 0, st->s, P,
+                       (uint32_t)total, d_packed);
+    JF_HIP(hipGetLastError());
+    JF_HIP(hipStreamSynchronize(st->s));   // the work buffers go out of scope
+    return JFHIP_OK;
+}
+
+int32_t srs_lagrange_points(const jfhip_srs* srs, uint32_t log_n, uint32_t blinders, uint32_t* d_packed, jfhip_stream* st) {
+    if (srs->curve == JFHIP_BN254) return srs_lagrange_points_t<Bn254G1>(srs, log_n, blinders, d_packed, st);
+    return srs_lagrange_points_t<Bls381G1>(srs, log_n, blinders, d_packed, st);
+}
+
 // give back the FK23 transforms a handle keeps (jfhip_srs_release_caches, jfhip_cache_clear, jfhip_srs_free)
 void srs_release_fk_cache(const jfhip_srs* srs) {
     std::vector<uint32_t*> drop;

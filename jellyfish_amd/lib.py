@@ -33,7 +33,7 @@ def library_path() -> str:
 SYMBOLS = [
     "jfhip_init", "jfhip_shutdown", "jfhip_cache_clear", "jfhip_stream_release_workspace", "jfhip_last_error", "jfhip_device_count", "jfhip_stream_create", "jfhip_stream_destroy",
     "jfhip_stream_sync", "jfhip_stream_raw", "jfhip_stream_wrap", "jfhip_srs_load", "jfhip_srs_load_device",
-    "jfhip_srs_load_serialized", "jfhip_msm_small",
+    "jfhip_srs_load_serialized", "jfhip_srs_lagrange", "jfhip_msm_small",
     "jfhip_srs_gen_for_testing", "jfhip_srs_free", "jfhip_srs_release_caches", "jfhip_srs_len", "jfhip_srs_window_bits", "jfhip_srs_read",
     "jfhip_msm", "jfhip_msm_batch", "jfhip_msm_batch_device", "jfhip_msm_device", "jfhip_msm_partial_device", "jfhip_msm_batch_partial_device", "jfhip_g1_sum_partials",
     "jfhip_kzg_open", "jfhip_kzg_multi_point_open", "jfhip_kzg_multi_open_rou", "jfhip_mle_open", "jfhip_mle_fold_device", "jfhip_ntt", "jfhip_ntt_device", "jfhip_plonk_quotient_turbo_device", "jfhip_plonk_quotient_ultra_device", "jfhip_plonk_quotient_coset_device", "jfhip_plonk_quotient_masked_device", "jfhip_plonk_perm_product_device", "jfhip_plonk_lookup_product_device", "jfhip_plonk_lookup_merge_device", "jfhip_plonk_lookup_sorted_device", "jfhip_witness_gather_device", "jfhip_poly_divide_linear_device", "jfhip_poly_divide_linear_noalloc_device",
@@ -187,6 +187,15 @@ class Srs:
         _check(load_library().jfhip_srs_gen_for_testing(curve, _p(beta), _p(g), ctypes.c_size_t(n), window_bits,
                                                         ctypes.byref(h)))
         return cls(h, curve)
+
+    def lagrange(self, log_n: int, blinders: int = 3, window_bits: int = 0) -> "Srs":
+        """a NEW handle: the Lagrange-basis commit key of the radix-2 domain of size 2^log_n, [L_i(beta)]g, followed by
+        `blinders` points [beta^(n+k)]g - [beta^k]g (jfhip_srs_lagrange): an MSM over (evaluations, blinders) on it is the
+        commitment of the blinded polynomial with those evaluations"""
+        h = ctypes.c_void_p()
+        _check(load_library().jfhip_srs_lagrange(self.h, ctypes.c_uint32(log_n), ctypes.c_uint32(blinders), window_bits,
+                                                 ctypes.byref(h)))
+        return Srs(h, self.curve)
 
     def __len__(self) -> int:
         return int(load_library().jfhip_srs_len(self.h))

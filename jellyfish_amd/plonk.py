@@ -403,9 +403,29 @@ class ProvingKey:
     # selector polynomials that are identically zero for this circuit (a gate kind it never uses): their coset
     # evaluations are zero, so prove() fills those rows instead of transforming them (same values, same proof bytes)
     selector_is_zero: tuple = ()
+    # optional: the Lagrange-basis form of the commit key for this domain ([L_i(beta)]g, then 3 vanishing-polynomial points;
+    # jfhip_srs_lagrange).  With it the round-1 commitments (wire polynomials, Plookup sorted polynomials) are MSMs over the
+    # witness VALUES and the blinders instead of over the coefficients the iFFT makes of them: the same group elements --
+    # the same proof bytes -- but witness values are often a few bits wide (counters, booleans, range-checked limbs), the
+    # bucket sort drops their zero digits, and the MSM costs a fraction of a dense one.  The reference commits the
+    # coefficient vectors (prover.rs:77-91, 99-124); a dense witness gains nothing and loses nothing.
+    lagrange_key: "L.Srs" = field(repr=False, default=None)
 
     def domain_size(self) -> int:
         return self.vk.domain_size
+
+    def keep_lagrange_commit_key(self) -> "ProvingKey":
+        """derive the Lagrange-basis commit key once (one group DFT of size n and a second window table; see lagrange_key)"""
+        if self.lagrange_key is None:
+            n = self.vk.domain_size
+            self.lagrange_key = self.commit_key.lagrange(n.bit_length() - 1, 3)
+        return self
+
+    def drop_lagrange_commit_key(self) -> "ProvingKey":
+        if self.lagrange_key is not None:
+            self.lagrange_key.free()
+            self.lagrange_key = None
+        return self
 
     def coset_evals_bytes(self) -> int:
         """HBM held by keep_coset_evals()"""
@@ -1153,6 +1173,10 @@ class PlonkKzgSnark:
         ck = prove_keys[first].commit_key    # run_3rd_round / compute_opening_proofs use prove_keys[0].commit_key
         commits = {i: _Committer(prove_keys[i].commit_key, cp, st, sharded, group) for i in mine}
         commit0 = commits[first]
+        # round-1 commitments from the witness values when the proving key holds the Lagrange-basis key (one GPU per
+        # commitment only: the sharded path partitions coefficient ranges)
+        lag_commits = {i: (_Committer(prove_keys[i].lagrange_key, cp, st) if (prove_keys[i].lagrange_key is not None
+                                                                              and not sharded) else None) for i in mine}
         if place.dist:
             from . import dist as jdist
 
@@ -1271,7 +1295,14 @@ class PlonkKzgSnark:
             wire_polys[:, :8] = _dev_fr(mont([(low[2 * j + t] - bs[j][t]) % r for j in range(W) for t in range(2)])).view(W, 8)
             wire_polys[:, n4:n4 + 8] = _dev_fr(mont([b for row in bs for b in row])).view(W, 8)
             tick("r1_mask")
-            comms_mine[i] = commits[i]([wire_polys[j] for j in range(W)], [n + 2] * W)
+            if lag_commits[i] is not None:
+                # the same commitments from the witness values: MSM over (w(1), w(omega), .., b_0, b_1) on the Lagrange key
+                lw = torch.empty(W, n4 + 8, dtype=torch.int64, device="cuda")
+                lw[:, :n4].copy_(wire_vals_v[i])
+                lw[:, n4:] = wire_polys[:, n4:n4 + 8]
+                comms_mine[i] = lag_commits[i]([lw[j] for j in range(W)], [n + 2] * W)
+            else:
+                comms_mine[i] = commits[i]([wire_polys[j] for j in range(W)], [n + 2] * W)
             tick("r1_commit")
             wire_polys_v[i] = wire_polys
             pub_poly_v[i] = buf[W]
@@ -1305,7 +1336,14 @@ class PlonkKzgSnark:
             apply_mask(h_polys[0], b1)
             apply_mask(h_polys[1], b2)
             tick("r1p_sorted_intt_mask")
-            h_comms_mine[i] = commits[i]([h_polys[0], h_polys[1]], [n + 3, n + 3])
+            if lag_commits[i] is not None:
+                lh = torch.empty(2, n4 + 12, dtype=torch.int64, device="cuda")
+                lh[0, :n4].copy_(srt[:n4])
+                lh[1, :n4].copy_(srt[n4 - 4:])
+                lh[:, n4:] = h_polys[:, n4:n4 + 12]
+                h_comms_mine[i] = lag_commits[i]([lh[0], lh[1]], [n + 3, n + 3])
+            else:
+                h_comms_mine[i] = commits[i]([h_polys[0], h_polys[1]], [n + 3, n + 3])
             tick("r1p_commit")
             h_polys_v[i], sorted_v[i], table_v[i], lkw_v[i] = h_polys, srt, merged[0], merged[1]
         h_comms_vec = place.gather(h_comms_mine, K) if any(lookup) else None

@@ -61,6 +61,14 @@ extern "C" {
         window_bits: i32,
         out: *mut *mut jfhip_srs,
     ) -> i32;
+    /// Lagrange-basis commit key of the domain of size 2^log_n (+ `blinders` vanishing-polynomial points), a new handle.
+    pub fn jfhip_srs_lagrange(
+        srs: *const jfhip_srs,
+        log_n: u32,
+        blinders: u32,
+        window_bits: i32,
+        out: *mut *mut jfhip_srs,
+    ) -> i32;
     pub fn jfhip_srs_load_serialized(
         curve_id: i32,
         bytes: *const u8,

@@ -53,6 +53,10 @@ def test_prove_matches_oracle_and_verifies(hip, cv, size):
     oproof, _, _ = P.prove(cv, P.test_rng(), ocs, opk)
     assert proof.as_dict() == oproof
     assert proof.serialize_compressed() == P.ser_proof(cv, oproof)
+    # round-1 commitments from the witness values on the Lagrange-basis commit key: same group elements, same bytes
+    pk.keep_lagrange_commit_key()
+    assert JP.PlonkKzgSnark.prove(JP.H.test_rng(), cs, pk).serialize_compressed() == P.ser_proof(cv, oproof)
+    pk.drop_lagrange_commit_key()
     # selector / sigma coset evaluations resident with the proving key: 7 transforms instead of 25, same bytes
     # (per slice of the quotient coset where the prover evaluates on slices, on the whole coset otherwise)
     pk.keep_coset_evals()
@@ -130,6 +134,9 @@ def test_bench_circuit_proof_verifies(hip, log_gates):
     assert sum(pk.selector_is_zero) == 9
     if log_gates > 20:
         return
+    pk.keep_lagrange_commit_key()   # the wires of this circuit hold counters, ones and zeros
+    assert JP.PlonkKzgSnark.prove(JP.H.test_rng(), cs, pk).serialize_compressed() == proof.serialize_compressed()
+    pk.drop_lagrange_commit_key()
     JP.SKIP_ZERO_POLYS = False
     try:
         assert JP.PlonkKzgSnark.prove(JP.H.test_rng(), cs, pk).serialize_compressed() == proof.serialize_compressed()

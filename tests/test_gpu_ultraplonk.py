@@ -74,6 +74,10 @@ def test_ultra_prove_matches_oracle_and_verifies(hip, cv, bits, size):
     assert proof.serialize_compressed() == P.ser_proof(cv, oproof)
     pub = cs.public_input()
     assert P.verify(cv, vk.as_dict(), pub, proof.as_dict(), trapdoor_beta=beta)
+    # wire and sorted-lookup commitments from evaluations on the Lagrange-basis commit key: same bytes
+    pk.keep_lagrange_commit_key()
+    assert JP.PlonkKzgSnark.prove(JP.H.test_rng(), cs, pk).serialize_compressed() == P.ser_proof(cv, oproof)
+    pk.drop_lagrange_commit_key()
     # resident coset evaluations (selectors, sigmas and the four Plookup tables): same bytes
     pk.keep_coset_evals()
     assert JP.PlonkKzgSnark.prove(JP.H.test_rng(), cs, pk).serialize_compressed() == P.ser_proof(cv, oproof)
