@@ -169,6 +169,15 @@ class DeviceSrs {  // HostOrDeviceSlice<IcicleAffine> of load_prover_param_to_gp
     }
     jfhip_srs* get() const { return h_; }
     size_t len() const { return jfhip_srs_len(h_); }
+    // The Lagrange-basis form of this key for the radix-2 domain of size 2^log_n, followed by `blinders` points
+    // [beta^(n+k)]g - [beta^k]g (jfhip_srs_lagrange; no counterpart in the reference): commit over (evaluations, blinders)
+    // on it equals the reference's commit to the blinded coefficient vector (prover.rs:77-91, 457-466).
+    Result<DeviceSrs<E>> lagrange(uint32_t log_n, uint32_t blinders) const {
+        jfhip_srs* h = nullptr;
+        int32_t rc = jfhip_srs_lagrange(h_, log_n, blinders, 0, &h);
+        if (rc) return last_error(rc);
+        return DeviceSrs<E>(h);
+    }
 
    private:
     jfhip_srs* h_ = nullptr;

@@ -212,6 +212,20 @@ static void run(const uint64_t* g_xy) {
         auto e3 = PCS::batch_open(srs.unwrap(), {rand_poly(3)}, {});
         CHECK(e3.is_err() && e3.unwrap_err().kind == PCSError::InvalidParameters);
     }
+    // Lagrange-basis key: commit over evaluations (+ zero blinders) == the oracle's commit to the iFFT's coefficients
+    {
+        auto lag = srs.unwrap().lagrange(10, 3);
+        CHECK(lag.is_ok() && lag.unwrap().len() == 1024 + 3);
+        std::vector<Fr> evals(1024);
+        for (auto& x : evals) x = rand_fr();
+        std::vector<Fr> coeffs = evals;
+        jfo_ntt(E::ID, coeffs[0].data(), 10, 1, 1, nullptr, 4);
+        std::vector<Fr> sc = evals;
+        sc.resize(1024 + 3);   // b_0 = b_1 = b_2 = 0
+        auto c = PCS::gpu_commit_with_loaded_prover_param(lag.unwrap(), DensePolynomial{sc}, stream.unwrap());
+        CHECK(c.is_ok() && c.unwrap() == cpu_commit(DensePolynomial{coeffs}));
+        CHECK(srs.unwrap().lagrange(13, 0).is_err());   // 2^13 points: more than the key holds
+    }
     // evaluation domain: ifft -> fft round trip, coset, against the oracle
     {
         auto dom = Radix2EvaluationDomain<E>::create(1000);
