@@ -414,11 +414,14 @@ class ProvingKey:
     def domain_size(self) -> int:
         return self.vk.domain_size
 
-    def keep_lagrange_commit_key(self) -> "ProvingKey":
-        """derive the Lagrange-basis commit key once (one group DFT of size n and a second window table; see lagrange_key)"""
+    def keep_lagrange_commit_key(self, window_bits: int = 0) -> "ProvingKey":
+        """derive the Lagrange-basis commit key once (one group DFT of size n and a second window table; see lagrange_key).
+        window_bits: the MSM window of that table (0: the library's choice for dense scalars of this length; a witness of
+        small values folds fewer buckets with a narrower window)"""
         if self.lagrange_key is None:
             n = self.vk.domain_size
-            self.lagrange_key = self.commit_key.lagrange(n.bit_length() - 1, 3)
+            wb = window_bits or int(os.environ.get("JF_LAGRANGE_WINDOW_BITS", "0"))
+            self.lagrange_key = self.commit_key.lagrange(n.bit_length() - 1, 3, wb)
         return self
 
     def drop_lagrange_commit_key(self) -> "ProvingKey":
