@@ -52,6 +52,10 @@ for ultra, curve, log_g, reps in ((False, 0, 14, 150), (True, 1, 13, 60), (False
     pk.keep_coset_evals()
     same("  the same with resident coset evaluations",
          lambda: JP.PlonkKzgSnark.prove(H.test_rng(), cs, pk, witness_mont=wit).serialize_compressed(), max(reps // 3, 5))
+    pk.keep_lagrange_commit_key()
+    same("  ... and round-1 commitments from the witness values (Lagrange-basis key)",
+         lambda: JP.PlonkKzgSnark.prove(H.test_rng(), cs, pk, witness_mont=wit).serialize_compressed(), max(reps // 3, 5))
+    pk.drop_lagrange_commit_key()
     del pk
 
 cv = R.BN254
