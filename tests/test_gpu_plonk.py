@@ -182,6 +182,13 @@ def test_batch_prove_matches_oracle_and_verifies(hip, cv):
     pks[1].keep_coset_evals()
     again = JP.PlonkKzgSnark.batch_prove(JP.H.test_rng(), css, pks, extra_transcript_init_msg=b"batch")
     assert again.serialize_compressed() == bp.serialize_compressed()
+    # Lagrange-basis round-1 commitments on some instances only: same bytes
+    pks[0].keep_lagrange_commit_key()
+    pks[2].keep_lagrange_commit_key()
+    again = JP.PlonkKzgSnark.batch_prove(JP.H.test_rng(), css, pks, extra_transcript_init_msg=b"batch")
+    assert again.serialize_compressed() == bp.serialize_compressed()
+    pks[0].drop_lagrange_commit_key()
+    pks[2].drop_lagrange_commit_key()
     # one instance: the BatchProof of prove()'s Proof
     one = JP.PlonkKzgSnark.batch_prove(JP.H.test_rng(), css[:1], pks[:1])
     single = JP.PlonkKzgSnark.prove(JP.H.test_rng(), css[0], pks[0])
