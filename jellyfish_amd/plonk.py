@@ -1176,10 +1176,10 @@ class PlonkKzgSnark:
         ck = prove_keys[first].commit_key    # run_3rd_round / compute_opening_proofs use prove_keys[0].commit_key
         commits = {i: _Committer(prove_keys[i].commit_key, cp, st, sharded, group) for i in mine}
         commit0 = commits[first]
-        # round-1 commitments from the witness values when the proving key holds the Lagrange-basis key (one GPU per
-        # commitment only: the sharded path partitions coefficient ranges)
-        lag_commits = {i: (_Committer(prove_keys[i].lagrange_key, cp, st) if (prove_keys[i].lagrange_key is not None
-                                                                              and not sharded) else None) for i in mine}
+        # round-1 commitments from the witness values when the proving key holds the Lagrange-basis key; sharded: the
+        # ranks partition the evaluation ranges exactly as they partition coefficient ranges on the monomial key
+        lag_commits = {i: (_Committer(prove_keys[i].lagrange_key, cp, st, sharded, group)
+                           if prove_keys[i].lagrange_key is not None else None) for i in mine}
         if place.dist:
             from . import dist as jdist
 

@@ -150,7 +150,10 @@ def _real_worker(rank, world, port, q, size=300):
         # the proving key keeps this rank's slice of the selector / sigma coset evaluations
         pk.keep_coset_evals(rank=rank, world=world)
         kept = JP.PlonkKzgSnark.prove(JP.H.test_rng(), cs, pk, sharded=True).serialize_compressed()
-        q.put((rank, ref == got and ref == kept))
+        # round-1 commitments from the witness values, the evaluation ranges partitioned over the ranks
+        pk.keep_lagrange_commit_key()
+        lag = JP.PlonkKzgSnark.prove(JP.H.test_rng(), cs, pk, sharded=True).serialize_compressed()
+        q.put((rank, ref == got and ref == kept and ref == lag))
     except Exception as e:
         q.put((rank, repr(e)))
     finally:
