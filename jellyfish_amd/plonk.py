@@ -1215,9 +1215,10 @@ class PlonkKzgSnark:
         def apply_mask(poly: torch.Tensor, b: list):
             """mask_polynomial (prover.rs:457-466): + (b_0 + .. + b_h X^h)(X^n - 1); poly has room for n + h + 1"""
             k = 4 * len(b)
-            low = _read_fr(cp, poly[:k])
-            poly[:k] = _dev_fr(mont([(x - y) % r for x, y in zip(low, b)]))
-            poly[n4:n4 + k] = _dev_fr(mont(b))
+            bdev = _dev_fr(mont(b))
+            # on the device (no read-back of the low coefficients: the host would wait for the iNTT and the device for the host)
+            poly[:k] = lincomb([(1, poly[:k], len(b)), (r - 1, bdev, len(b))], len(b))
+            poly[n4:n4 + k] = bdev
 
         def lincomb(terms, out_len: int) -> torch.Tensor:
             """sum_k s_k * poly_k for (scalar, device poly, length) terms; jfhip_poly_lincomb_device takes <= 32
@@ -1293,10 +1294,9 @@ class PlonkKzgSnark:
             buf = bufs[i]
             wire_polys = torch.zeros(W, l4, dtype=torch.int64, device="cuda")
             wire_polys[:, :n4].copy_(buf[:W])
-            # mask_polynomial for the W wire polynomials with ONE read-back and two uploads
-            low = _read_fr(cp, wire_polys[:, :8].contiguous().view(-1))
-            wire_polys[:, :8] = _dev_fr(mont([(low[2 * j + t] - bs[j][t]) % r for j in range(W) for t in range(2)])).view(W, 8)
-            wire_polys[:, n4:n4 + 8] = _dev_fr(mont([b for row in bs for b in row])).view(W, 8)
+            # mask_polynomial for the W wire polynomials, on the device
+            for j in range(W):
+                apply_mask(wire_polys[j], bs[j])
             tick("r1_mask")
             if lag_commits[i] is not None:
                 # the same commitments from the witness values: MSM over (w(1), w(omega), .., b_0, b_1) on the Lagrange key
