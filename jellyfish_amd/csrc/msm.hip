@@ -1512,6 +1512,10 @@ int choose_window_bits(int32_t curve, size_t n) {
             best = c;
         }
     }
+    // BN254 around 2^21 points (the per-GPU shard of the metric's MSM on 8 GPUs): the model picks c = 20 (13 windows, three
+    // sort levels, 2^19 buckets to fold); measured (scripts/window_sweep.py 21) c = 15 3.58 ms, 16 3.29, 17 3.05, 18 3.36,
+    // 19 3.57, 20 3.29-3.32, 21 3.59: two sort levels and a 1.9 GiB table (inside the translation reach) win
+    if (curve == JFHIP_BN254 && n > ((size_t)3 << 19) && n <= ((size_t)5 << 19)) best = 17;
     // BLS12-381: the 12-limb fold / fix-up tails weigh more than the model says around 2^20 points; measured
     // (scripts/msm_probe_bls.py) 2^20: c = 16 5.3 ms, 18 5.5, 19 6.1; 2^21: c = 20 8.4 ms, 19 9.6, 18 9.6; 2^22: c = 20
     if (curve != JFHIP_BN254) {
